@@ -1,0 +1,179 @@
+"""Golden-vector case table shared by tools/gen_golden.py (which runs the unmodified
+reference on CPU in the build container) and the parity tests (which run the oracle
+and the HIP path on the same regenerated inputs).
+
+Inputs are never stored: every case is rebuilt from its seed with the build's own
+generator (zest-nerf_amd/zest_synth.py).  Only expected OUTPUTS are committed, as
+tests/golden/<case>.npz.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "zest-nerf_amd")
+if PKG not in sys.path:
+    sys.path.insert(0, PKG)
+
+import zest_synth as zs  # noqa: E402
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+PE_PTS, PE_XYZT, PE_DIR = 63, 84, 27
+
+
+# ----------------------------------------------------------------- op-level cases
+def composite_inputs(seed, R=6, S=16, dead_ray=True):
+    g = zs.rng(seed)
+    raw = (g.standard_normal((R, S, 4)) * 2.0).astype(np.float32)
+    if dead_ray:
+        raw[1, :, 3] = -1.0          # sigma <= 0 everywhere: zero weights
+        raw[2, :, 3] = 40.0          # opaque at the first sample
+    z = np.sort(g.uniform(2, 6, size=(R, S)).astype(np.float32), -1)
+    d = np.stack([g.uniform(-.5, .5, R), g.uniform(-.5, .5, R), np.ones(R)], -1).astype(np.float32)
+    return dict(raw=raw, z=z, rays_dir=d)
+
+
+def blend_inputs(seed, R=5, S=24):
+    g = zs.rng(seed)
+    raw_dy = (g.standard_normal((R, S, 4)) * 2.0).astype(np.float32)
+    raw_st = (g.standard_normal((R, S, 4)) * 2.0).astype(np.float32)
+    blend = g.uniform(0, 1, size=(R, S)).astype(np.float32)
+    blend[0] = 0.0
+    blend[1] = 1.0
+    z = np.sort(g.uniform(2, 6, size=(R, S)).astype(np.float32), -1)
+    d = np.stack([g.uniform(-.5, .5, R), g.uniform(-.5, .5, R), np.ones(R)], -1).astype(np.float32)
+    return dict(raw_dy=raw_dy, raw_st=raw_st, blend=blend, z=z, rays_dir=d)
+
+
+def embed_inputs(seed, C, M=40):
+    g = zs.rng(seed)
+    x = g.uniform(-0.4, 1.3, size=(M, C)).astype(np.float32)
+    x[0] = 0.0
+    x[1] = 1.0
+    x[2] = 0.999
+    x[3] = -0.3
+    return dict(x=x)
+
+
+def volume_inputs(seed, dims=(6, 7, 9), M=200):
+    g = zs.rng(seed)
+    vol = g.standard_normal((1, 8) + tuple(dims), dtype=np.float32)
+    ndc = g.uniform(-0.15, 1.15, size=(1, 4, M // 4, 3)).astype(np.float32)
+    ndc[0, 0, 0] = (0.0, 0.0, 0.0)
+    ndc[0, 0, 1] = (1.0, 1.0, 1.0)
+    ndc[0, 0, 2] = (0.5, 0.5, 0.5)
+    ndc[0, 0, 3] = (1.0, 0.0, 0.25)
+    return dict(volume=vol, ndc=ndc)
+
+
+def color_inputs(seed, V=3, H=10, W=14, R=6, S=20):
+    g = zs.rng(seed)
+    imgs = g.uniform(0, 1, size=(1, V, 3, H, W)).astype(np.float32)
+    w2cs, intr = zs.make_cameras(V + 1, H, W, focal=12.0, spread=0.3)
+    pts = np.empty((1, R, S, 3), np.float32)
+    pts[..., 0] = g.uniform(-3.5, 3.5, size=(1, R, S))
+    pts[..., 1] = g.uniform(-2.5, 2.5, size=(1, R, S))
+    pts[..., 2] = g.uniform(1.5, 6.0, size=(1, R, S))
+    pts[0, 0, 0] = (0.0, 0.0, -2.0)      # behind the cameras
+    pts[0, 0, 1] = (40.0, 0.0, 3.0)      # far outside the frame (border clamp, mask 0)
+    return dict(imgs=imgs, w2cs=w2cs, intrinsics=intr, pts=pts)
+
+
+MLP_VARIANTS = {
+    # name: (in_ch_pts, in_ch_feat, sceneflow, static, use_mvs, net_type)
+    "static_mvs20": (PE_PTS, 20, False, True, True, "v0"),
+    "static_nomvs": (PE_PTS, 20, False, True, False, "v0"),
+    "static_sf_mvs40": (PE_PTS, 40, True, True, True, "v0"),
+    "dynamic_mvs24": (PE_XYZT, 24, True, False, True, "v0"),
+    "dynamic_nomvs": (PE_XYZT, 24, True, False, False, "v0"),
+    "v2_mvs20": (PE_PTS, 20, False, True, True, "v2"),
+}
+
+
+def mlp_inputs(seed, variant, M=64):
+    P, Fd, sf, st, mvs, nt = MLP_VARIANTS[variant]
+    lay = zs.mlp_layout(P, PE_DIR, Fd, sf and nt == "v0", st, mvs)
+    state = zs.fill_mlp_state(lay, seed)
+    g = zs.rng(seed + 1000)
+    in_ch = P + (Fd if (mvs or nt == "v2") else 0) + PE_DIR
+    x = g.uniform(-1, 1, size=(1, M, in_ch)).astype(np.float32)
+    return dict(state=state, x=x, P=P, Fd=Fd, sceneflow=sf, static=st, use_mvs=mvs, net_type=nt)
+
+
+# --------------------------------------------------------------- rendering cases
+def render_inputs(seed, R=32, S=16, V=3, use_mvs=True, scene_flow=False, use_mvs_dy=True,
+                  lively=True):
+    """Small scene (24x32 images, 8x10x12 volume) + seeded MLP weights."""
+    sc = zs.make_scene(seed, R, S, H=24, W=32, V=V, V_dy=4, pad=2, vol_depth=8, focal=30.0,
+                       static_volume=use_mvs, dynamic=scene_flow)
+    feat_dim = 8 + 4 * V
+    lay_s = zs.mlp_layout(PE_PTS, PE_DIR, feat_dim, scene_flow, True, use_mvs)
+    sc["state_static"] = zs.fill_mlp_state(lay_s, seed + 1, lively=lively)
+    sc.update(feat_dim=feat_dim, feat_dim_dy=24, use_mvs=use_mvs, use_mvs_dy=use_mvs_dy,
+              scene_flow=scene_flow)
+    if scene_flow:
+        lay_d = zs.mlp_layout(PE_XYZT, PE_DIR, 24, True, False, use_mvs_dy)
+        sc["state_dynamic"] = zs.fill_mlp_state(lay_d, seed + 2, lively=lively)
+        g = zs.rng(seed + 3)
+        sc["noise_static"] = g.standard_normal((R, S)).astype(np.float32)
+        sc["noise_blend"] = g.standard_normal((R, S)).astype(np.float32)
+        if not use_mvs_dy:
+            sc.pop("vol_dynamic")
+    return sc
+
+
+CASES = {
+    "composite": dict(kind="composite", seed=11),
+    "composite_white": dict(kind="composite", seed=12, white_bkgd=True),
+    "blend": dict(kind="blend", seed=13),
+    "embed3x10": dict(kind="embed", seed=14, C=3, L=10),
+    "embed4x10": dict(kind="embed", seed=15, C=4, L=10),
+    "embed3x4": dict(kind="embed", seed=16, C=3, L=4),
+    "volume": dict(kind="volume", seed=17),
+    "color": dict(kind="color", seed=18),
+    **{"mlp_" + k: dict(kind="mlp", seed=20 + i, variant=k) for i, k in enumerate(MLP_VARIANTS)},
+    "render_static_mvs": dict(kind="render", seed=31, use_mvs=True),
+    "render_static_nomvs": dict(kind="render", seed=32, use_mvs=False),
+    "render_static_white": dict(kind="render", seed=33, use_mvs=True, white_bkgd=True),
+    "render_zest_val": dict(kind="render", seed=34, scene_flow=True, val=True),
+    "render_zest_train": dict(kind="render", seed=35, scene_flow=True),
+    "render_zest_bwd": dict(kind="render", seed=36, scene_flow=True, chain_bwd=True),
+    "render_zest_5f": dict(kind="render", seed=37, scene_flow=True, chain_5frames=True),
+    "render_zest_bwd5f": dict(kind="render", seed=38, scene_flow=True, chain_bwd=True,
+                              chain_5frames=True),
+    "render_zest_noise": dict(kind="render", seed=39, scene_flow=True, chain_5frames=True,
+                              raw_noise_std=1.0),
+    "render_zest_nomvsdy": dict(kind="render", seed=40, scene_flow=True, val=True,
+                                use_mvs_dy=False),
+}
+
+REF_FRAME_IDX, NUM_FRAMES = 0.1, 24
+
+
+def build(case):
+    c = CASES[case]
+    k = c["kind"]
+    if k == "composite":
+        return composite_inputs(c["seed"])
+    if k == "blend":
+        return blend_inputs(c["seed"])
+    if k == "embed":
+        return embed_inputs(c["seed"], c["C"])
+    if k == "volume":
+        return volume_inputs(c["seed"])
+    if k == "color":
+        return color_inputs(c["seed"])
+    if k == "mlp":
+        return mlp_inputs(c["seed"], c["variant"])
+    if k == "render":
+        return render_inputs(c["seed"], use_mvs=c.get("use_mvs", True),
+                             scene_flow=c.get("scene_flow", False),
+                             use_mvs_dy=c.get("use_mvs_dy", True))
+    raise KeyError(k)
+
+
+def load_golden(case):
+    with np.load(os.path.join(GOLDEN_DIR, case + ".npz"), allow_pickle=False) as f:
+        return {k: f[k] for k in f.files}

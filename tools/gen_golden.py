@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference on CPU.
+
+Runs only in the build container (needs /root/reference).  The reference modules
+`renderer`, `utils`, `networks` import four packages that are absent here and are
+not used on the rendering path (cv2, torchvision, kornia, inplace_abn; SURVEY.md
+section 8(c)); empty placeholder modules are registered for them before import.
+Inputs and weights come from the build's own seeded generator
+(tests/golden_cases.py + zest-nerf_amd/zest_synth.py); only the reference's OUTPUTS
+are written.  Nothing from the reference's source is copied.
+
+    python tools/gen_golden.py            # all cases
+    python tools/gen_golden.py render_    # cases whose name contains the substring
+"""
+import os
+import sys
+import types
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import golden_cases as gc  # noqa: E402
+
+REF = "/root/reference"
+
+
+def _placeholders():
+    def mod(name):
+        m = types.ModuleType(name)
+        sys.modules[name] = m
+        return m
+    mod("cv2").COLORMAP_JET = 2                        # default arg of an off-path viz helper
+    tv = mod("torchvision")
+    tv.transforms = mod("torchvision.transforms")
+    tv.utils = mod("torchvision.utils")
+    k = mod("kornia")
+    k.utils = mod("kornia.utils")
+    k.utils.create_meshgrid = lambda *a, **kw: None   # only homo_warp uses it (off-path)
+    abn = mod("inplace_abn")
+
+    class InPlaceABN(torch.nn.Module):                # default arg of off-path CNN blocks
+        pass
+    abn.InPlaceABN = InPlaceABN
+
+
+def import_reference():
+    _placeholders()
+    sys.path.insert(0, REF)
+    mods = {}
+    for n in ("utils", "renderer", "networks"):
+        sys.modules.pop(n, None)
+    import renderer as r
+    import utils as u
+    import networks as nw
+    mods.update(renderer=r, utils=u, networks=nw)
+    sys.path.remove(REF)
+    return SimpleNamespace(**mods)
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def ref_net(ref, state, P, Fd, sceneflow, static, use_mvs, net_type="v0"):
+    net = ref.networks.MVSNeRF(D=8, W=256, input_ch_pts=P, output_ch=4, input_ch_views=gc.PE_DIR,
+                               input_ch_feat=Fd, skips=[4], net_type=net_type,
+                               sceneflow=sceneflow, static=static, use_mvs=use_mvs)
+    missing = net.load_state_dict({k: T(v) for k, v in state.items()}, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return net.eval()
+
+
+def run_case(ref, name):
+    c = gc.CASES[name]
+    inp = gc.build(name)
+    k = c["kind"]
+    out = {}
+    with torch.no_grad():
+        if k == "composite":
+            z, d = T(inp["z"])[None], T(inp["rays_dir"])[None]
+            dists = ref.renderer.depth2dist(z, torch.norm(d, dim=-1, keepdim=True))
+            r = ref.renderer.raw2outputs(T(inp["raw"])[None], z, dists,
+                                         white_bkgd=c.get("white_bkgd", False))
+            for n, v in zip(("rgb_map", "disp_map", "acc_map", "weights", "depth_map", "alpha"), r):
+                out[n] = v[0].numpy()
+            out["dists"] = dists[0].numpy()
+        elif k == "blend":
+            z, d = T(inp["z"])[None], T(inp["rays_dir"])[None]
+            dists = ref.renderer.depth2dist(z, torch.norm(d, dim=-1, keepdim=True))
+            r = ref.renderer.raw2outputs_blending(T(inp["raw_dy"])[None], T(inp["raw_st"])[None],
+                                                  T(inp["blend"])[None], z, dists)
+            for n, v in zip(("rgb_map", "depth_map", "rgb_map_fg", "depth_map_fg", "weights_fg",
+                             "weights_dy"), r):
+                out[n] = v[0].numpy()
+        elif k == "embed":
+            e = ref.networks.Embedding(c["C"], c["L"])
+            out["y"] = e(T(inp["x"])).numpy()
+            out["freq_bands"] = e.freq_bands.numpy()
+        elif k == "volume":
+            out["feat"] = ref.utils.index_point_feature(T(inp["volume"]), T(inp["ndc"])).numpy()[0]
+        elif k == "color":
+            poses = {"w2cs": T(inp["w2cs"]), "intrinsics": T(inp["intrinsics"])}
+            out["colors"] = ref.utils.build_color_volume(T(inp["pts"]), poses, T(inp["imgs"]),
+                                                         with_mask=True).numpy()[0]
+        elif k == "mlp":
+            net = ref_net(ref, inp["state"], inp["P"], inp["Fd"], inp["sceneflow"], inp["static"],
+                          inp["use_mvs"], inp["net_type"])
+            out["y"] = net(T(inp["x"])).numpy()[0]
+        elif k == "render":
+            out = run_render(ref, c, inp)
+    return out
+
+
+def run_render(ref, c, sc):
+    sf = c.get("scene_flow", False)
+    args = SimpleNamespace(netchunk=1024, feat_dim=sc["feat_dim"], feat_dim_dy=sc["feat_dim_dy"],
+                           img_downscale=1.0, use_color_volume=False, net_type="v0")
+    e_pts = ref.networks.Embedding(3, 10)
+    e_xyzt = ref.networks.Embedding(4, 10)
+    e_dir = ref.networks.Embedding(3, 4)
+    net_s = ref_net(ref, sc["state_static"], gc.PE_PTS, sc["feat_dim"], sf, True, sc["use_mvs"])
+    net_d = None
+    if sf:
+        net_d = ref_net(ref, sc["state_dynamic"], gc.PE_XYZT, 24, True, False, sc["use_mvs_dy"])
+    cam = {"w2cs": T(sc["w2cs"]), "intrinsics": T(sc["intrinsics"])}
+    nb_cam = None
+    if sf and sc["use_mvs_dy"]:
+        nb_cam = {"w2cs": T(sc["nb_w2cs"]), "intrinsics": T(sc["nb_intrinsics"])}
+    std = c.get("raw_noise_std", 0)
+    queue = [T(sc["noise_static"])[None], T(sc["noise_blend"])[None]] if sf else []
+    real_randn = torch.randn
+
+    def fake_randn(shape, *a, **kw):       # inject the two density-noise draws, in call order
+        n = queue.pop(0)
+        assert tuple(n.shape) == tuple(shape), (n.shape, shape)
+        return n
+    torch.randn = fake_randn
+    try:
+        ret = ref.renderer.rendering(
+            args, T(sc["rays_pts"]), T(sc["rays_ndc"]), T(sc["depth_candidates"]), T(sc["rays_dir"]),
+            volume_feature_static=T(sc["vol_static"]) if sc["use_mvs"] else None,
+            volume_feature_dynamic=T(sc["vol_dynamic"]) if (sf and sc["use_mvs_dy"]) else None,
+            imgs=T(sc["imgs"]) if sc["use_mvs"] else None,
+            neighbour_frames=T(sc["nb_imgs"]) if (sf and sc["use_mvs_dy"]) else None,
+            im_cam_mat=cam, nb_cam_mat=nb_cam, network_fn=net_s, network_fn_dy=net_d,
+            embedding_pts=e_pts, embedding_xyzt=e_xyzt, embedding_dir=e_dir,
+            chain_bwd=c.get("chain_bwd", False), chain_5frames=c.get("chain_5frames", False),
+            ref_frame_idx=gc.REF_FRAME_IDX, num_frames=gc.NUM_FRAMES,
+            white_bkgd=c.get("white_bkgd", False), scene_flow=sf, val=c.get("val", False),
+            raw_noise_std=std)
+    finally:
+        torch.randn = real_randn
+    out = {}
+    for kk, v in ret.items():
+        if v is not None:
+            out[kk] = v[0].numpy()
+    out["__keys__"] = np.array(sorted(ret.keys()))
+    out["__none_keys__"] = np.array(sorted(kk for kk, v in ret.items() if v is None) or [""])
+    return out
+
+
+def main():
+    sel = sys.argv[1] if len(sys.argv) > 1 else ""
+    ref = import_reference()
+    os.makedirs(gc.GOLDEN_DIR, exist_ok=True)
+    for name in gc.CASES:
+        if sel not in name:
+            continue
+        out = run_case(ref, name)
+        path = os.path.join(gc.GOLDEN_DIR, name + ".npz")
+        np.savez_compressed(path, **out)
+        print("%-24s %3d arrays %7.1f KB" % (name, len(out), os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__":
+    main()

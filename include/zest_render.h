@@ -1,0 +1,174 @@
+/*
+ * zest_render.h — C ABI of the MI355X (gfx950) ZeST-NeRF volume-rendering library.
+ *
+ * The reference (violetamenendez/zest-nerf) has no FFI: its hot path is bound by
+ * Python import (`from renderer import rendering`, train.py:44; `from utils import
+ * ...`, renderer.py:20; networks.py:25-26).  This header is the drop-in boundary
+ * underneath that Python surface: each entry point replaces the device work of one
+ * reference function, takes plain device pointers + sizes + a HIP stream, allocates
+ * nothing the caller sees, never synchronises, and returns a hipError_t as int
+ * (0 = success).  `zest_last_error()` gives the message for the calling thread.
+ *
+ * All tensors are dense row-major fp32 unless stated; R = rays, S = samples per ray,
+ * M = R*S flattened samples, V = source views.  Inputs are never written.
+ * INTEGRATION.md shows the ctypes binding (zest-nerf_amd/zest_hip.py) a maintainer of
+ * the reference would add.
+ */
+#ifndef ZEST_RENDER_H
+#define ZEST_RENDER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZEST_ABI_VERSION 1
+
+/* arithmetic of the MLP contraction */
+#define ZEST_PREC_F32  0   /* v_mfma_f32_32x32x2_f32: exact fp32 products, parity mode */
+#define ZEST_PREC_BF16 1   /* v_mfma_f32_32x32x16_bf16: bf16 operands, fp32 accumulate  */
+
+/* extra heads of the MLP (reference networks.py:115-123) */
+#define ZEST_HEAD_NONE    0  /* out = rgb(3) sigma(1)                                     */
+#define ZEST_HEAD_BLEND   1  /* static net with scene flow: + sigmoid(w_linear)   -> 5   */
+#define ZEST_HEAD_DYNAMIC 2  /* dynamic net: + tanh(sf_linear)(6) sigmoid(prob)(2) -> 12 */
+
+/* Shape of one width-256, depth-8, skip-at-4 NeRF MLP
+ * (reference networks.py:73-132 `Renderer`, :223-265 `Renderer_linear`). */
+typedef struct zest_mlp_desc {
+    int32_t in_ch_pts;    /* encoded point width: 63 (xyz, L=10) or 84 (xyzt)            */
+    int32_t in_ch_feat;   /* F = 8 + 4V per-sample feature width (ignored if !use_feat)   */
+    int32_t in_ch_views;  /* encoded direction width: 27                                  */
+    int32_t use_feat;     /* 1: input carries features, trunk is modulated by pts_bias    */
+    int32_t net_type;     /* 0 = 'v0' multiplicative modulation; 2 = 'v2' additive,       */
+                          /*     relu(alpha), sigmoid(rgb)                                */
+    int32_t head;         /* ZEST_HEAD_*                                                   */
+} zest_mlp_desc;
+
+/* Parameter order for zest_mlp_pack: weight then bias of each nn.Linear, [out,in]
+ * row-major fp32 exactly as in the reference state dict. */
+enum {
+    ZEST_P_PTS0 = 0,          /* pts_linears.0 .. pts_linears.7 -> 0..7 */
+    ZEST_P_PTS_BIAS = 8,      /* pts_bias        [256, F]              */
+    ZEST_P_VIEWS = 9,         /* views_linears.0 [128, 256+27]         */
+    ZEST_P_FEATURE = 10,      /* feature_linear  [256, 256]            */
+    ZEST_P_ALPHA = 11,        /* alpha_linear    [1, 256]              */
+    ZEST_P_RGB = 12,          /* rgb_linear      [3, 128]              */
+    ZEST_P_HEAD0 = 13,        /* w_linear [1,256]  | sf_linear [6,256] */
+    ZEST_P_HEAD1 = 14,        /* (unused)          | prob_linear [2,256] */
+    ZEST_P_COUNT = 15
+};
+
+int         zest_abi_version(void);
+const char *zest_last_error(void);
+/* number of compute units / multiprocessor clock (kHz) of the current device */
+int         zest_device_info(int *cu_count, int *clock_khz, char *name, size_t name_len);
+
+/* ---- compositing -------------------------------------------------------------
+ * Replaces depth2dist + raw2outputs + raw2alpha (reference renderer.py:74-164).
+ * raw [R,S,4] (rgb logits, sigma), z [R,S], rays_dir [R,3] (un-normalised; the
+ * sample distance is dz * |dir|, last sample 1e10*|dir|).  noise [R,S] or NULL is
+ * added to sigma after scaling by noise_std.  Any output pointer may be NULL.
+ * rgb_map [R,3], depth/acc/disp [R], weights/alpha [R,S]. */
+int zest_composite_fwd(const float *raw, const float *z, const float *rays_dir,
+                       const float *noise, float noise_std, int white_bkgd,
+                       int R, int S,
+                       float *rgb_map, float *depth_map, float *acc_map, float *disp_map,
+                       float *weights, float *alpha, void *stream);
+
+/* Replaces raw2outputs_blending (reference renderer.py:166-219).
+ * raw_dy, raw_st [R,S,4]; blend [R,S].  Outputs: blended rgb_map [R,3], depth_map [R];
+ * dynamic-only rgb_map_fg [R,3], depth_map_fg [R], weights_fg [R,S]; weights_dy [R,S]
+ * (dynamic share of the blended weights) and its per-ray sum weights_dd_sum [R]. */
+int zest_composite_blend_fwd(const float *raw_dy, const float *raw_st, const float *blend,
+                             const float *z, const float *rays_dir,
+                             const float *noise, float noise_std, int R, int S,
+                             float *rgb_map, float *depth_map, float *rgb_map_fg,
+                             float *depth_map_fg, float *weights_fg, float *weights_dy,
+                             float *weights_dd_sum, void *stream);
+
+/* Weighted per-ray sum  out[r] = sum_s w[r,s] * (1 - p[r,s])
+ * (compute_2d_prob, reference renderer.py:22-32). */
+int zest_weighted_complement_sum(const float *w, const float *p, int R, int S, float *out,
+                                 void *stream);
+
+/* ---- per-sample operators -------------------------------------------------------
+ * Positional encoding, Embedding.forward (reference networks.py:48-65), log-scale
+ * bands 2^0..2^(L-1):  x [M,C] -> y [M, C*(2L+1)]. */
+int zest_embed_fwd(const float *x, int M, int C, int L, float *y, void *stream);
+
+/* One-off layout changes made when a volume / image set is first seen:
+ * volume [8,D,H,W] -> channels-last [D,H,W,8] (one 32-byte read per trilinear corner);
+ * imgs [V,3,H,W] -> [V,H,W,4] (rgb + pad, one 16-byte read per bilinear corner). */
+int zest_volume_to_cl(const float *vol, int D, int H, int W, float *vol_cl, void *stream);
+int zest_images_to_cl(const float *imgs, int V, int H, int W, float *imgs_cl, void *stream);
+
+/* Trilinear lookup, zero padding, align_corners: index_point_feature
+ * (reference utils.py:433-459).  vol_cl [D,H,W,8]; ndc [M,3] -> out [M,8]. */
+int zest_volume_lookup_fwd(const float *vol_cl, int D, int H, int W, const float *ndc, int M,
+                           float *out, void *stream);
+
+/* Per-view projection + bilinear colour (border clamp) + strict in-frame mask:
+ * build_color_volume(with_mask=True) + get_ndc_coordinate (reference utils.py:461-505,
+ * 262-269).  imgs_cl [V,H,W,4]; w2cs [>=V,4,4]; intrinsics [>=V,3,3]; pts [M,3] world
+ * -> out [M,4V] as (r,g,b,mask) per view. */
+int zest_color_lookup_fwd(const float *imgs_cl, int V, int H, int W, const float *w2cs,
+                          const float *intrinsics, const float *pts, int M, float *out,
+                          void *stream);
+
+/* Assemble the MLP input exactly as prepare_pts / prepare_dynamic_pts do (reference
+ * renderer.py:246-318): x[m] = PE_L10(ndc[,t]) | vol(8) | colours(4V) | PE_L4(dir_ref).
+ * ndc, pts [R,S,3]; rays_dir [R,3]; w2cs/intrinsics of the view set (view 0 rotates the
+ * direction, renderer.py:256-258); has_time appends the constant frame index t as 4th
+ * coordinate; vol_cl/imgs_cl NULL => no feature columns; w2cs NULL => direction is not
+ * rotated.  x [R*S, C_in]. */
+int zest_encode_fwd(const float *ndc, const float *pts, const float *rays_dir, int R, int S,
+                    int has_time, float t,
+                    const float *vol_cl, int D, int Hv, int Wv,
+                    const float *imgs_cl, int V, int H, int W,
+                    const float *w2cs, const float *intrinsics,
+                    float *x, void *stream);
+
+/* ---- MLP ---------------------------------------------------------------------------
+ * Weights are re-packed once per parameter update into the order the MFMA engine
+ * streams them.  zest_mlp_packed_bytes gives the buffer size; params is an array of
+ * 2*ZEST_P_COUNT device pointers (weight, bias per ZEST_P_* slot, NULL where absent). */
+size_t zest_mlp_packed_bytes(const zest_mlp_desc *desc, int precision);
+int    zest_mlp_pack(const zest_mlp_desc *desc, int precision, const float *const *params,
+                     void *packed, void *stream);
+
+/* MVSNeRF.forward / Renderer.forward (reference networks.py:150-221, 283-319):
+ * x [M, C_in] -> out [M, C_out], C_out = 4 | 5 | 12 by desc->head. */
+int zest_mlp_fwd(const zest_mlp_desc *desc, int precision, const void *packed,
+                 const float *x, int M, float *out, void *stream);
+
+/* ---- fused inference path ---------------------------------------------------------
+ * One launch for rendering(..., val=True) (reference renderer.py:579-626 with the
+ * early return at :444-445): encode + feature gathers + static MLP [+ dynamic MLP]
+ * + compositing, nothing per-sample written to HBM.
+ * out [R,16]: 0-2 rgb_map, 3 depth_map, 4 acc_map; with the dynamic net also
+ * 5-7 rgb_map_ref, 8 depth_map_ref, 9-11 rgb_map_ref_dy, 12 depth_map_ref_dy,
+ * 13 weights_map_dd; 14,15 reserved. */
+typedef struct zest_view_set {
+    const float *vol_cl;      /* [D,Hv,Wv,8] or NULL */
+    int32_t D, Hv, Wv;
+    const float *imgs_cl;     /* [V,H,W,4] or NULL   */
+    int32_t V, H, W;
+    const float *w2cs;        /* [>=max(V,1),4,4] or NULL */
+    const float *intrinsics;  /* [>=V,3,3]           */
+} zest_view_set;
+
+int zest_render_fused_fwd(const float *ndc, const float *pts, const float *z,
+                          const float *rays_dir, int R, int S,
+                          const zest_mlp_desc *desc_static, const void *packed_static,
+                          const zest_view_set *views_static,
+                          const zest_mlp_desc *desc_dynamic, const void *packed_dynamic,
+                          const zest_view_set *views_dynamic, float frame_idx,
+                          int precision, int white_bkgd, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZEST_RENDER_H */

@@ -1,0 +1,45 @@
+"""CPU: the C-ABI library loads and exports every symbol include/zest_render.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "zest_render.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(zest_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    import zest_hip
+    assert sorted(zest_hip.exported_symbols()) == _declared()
+
+
+def test_library_exports_every_declared_symbol():
+    import zest_hip
+    if not os.path.exists(zest_hip.LIB_PATH):
+        import build_hip
+        build_hip.build()
+    lib = ctypes.CDLL(zest_hip.LIB_PATH)
+    for name in _declared():
+        assert hasattr(lib, name), name
+    assert lib.zest_abi_version() == 1
+
+
+def test_missing_library_is_an_error(monkeypatch):
+    import zest_hip
+    monkeypatch.setattr(zest_hip, "_lib", None)
+    monkeypatch.setattr(zest_hip, "LIB_PATH", "/nonexistent/libzest_hip.so")
+    with pytest.raises(RuntimeError, match="no non-HIP execution path"):
+        zest_hip.lib()
+
+
+def test_cpu_tensors_are_rejected():
+    import torch
+    import zest_hip
+    with pytest.raises(RuntimeError, match="runs only on a HIP device"):
+        zest_hip.embed(torch.zeros(4, 3), 10)

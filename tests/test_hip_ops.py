@@ -1,0 +1,152 @@
+"""GPU: each HIP operator against the reference-generated golden vectors and the oracle.
+
+Tolerance for fp32 work is BASELINE.json's: 1e-4 abs + 1e-3 rel.  The bf16 MLP is a
+throughput mode with bf16 operands (8 significant bits) and is held to 3e-2 abs + 3e-2 rel
+of the output scale, stated per test.
+"""
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+import oracle_run
+
+pytestmark = pytest.mark.gpu
+ATOL, RTOL = 1e-4, 1e-3
+DEV = "cuda:0"
+
+
+def G(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def close(got, want, atol=ATOL, rtol=RTOL, name=""):
+    got = got.detach().double().cpu().numpy() if torch.is_tensor(got) else np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    both_nan = np.isnan(got) & np.isnan(want)
+    err = np.where(both_nan, 0, np.abs(got - want))
+    tol = atol + rtol * np.abs(np.where(both_nan, 0, want))
+    bad = err > tol
+    assert not bad.any(), "%s: %d/%d outside tolerance, max err %.3g at |ref| %.3g" % (
+        name, bad.sum(), bad.size, err.max(), np.abs(want).flat[np.nanargmax(err)])
+
+
+@pytest.mark.parametrize("case", ["composite", "composite_white"])
+def test_composite(hip, case):
+    import zest_hip
+    inp, gold = gc.build(case), gc.load_golden(case)
+    r = zest_hip.composite(G(inp["raw"]), G(inp["z"]), G(inp["rays_dir"]),
+                           white_bkgd=gc.CASES[case].get("white_bkgd", False))
+    for n, v in zip(("rgb_map", "disp_map", "acc_map", "weights", "depth_map", "alpha"), r):
+        close(v, gold[n], name=n)
+
+
+def test_composite_noise_and_properties(hip):
+    import zest_hip
+    inp = gc.composite_inputs(101, R=37, S=150, dead_ray=True)     # ragged: 150 = 2*64 + 22
+    noise = gc.zs.rng(5).standard_normal((37, 150)).astype(np.float32)
+    from oracle import zest_oracle as zo
+    z, d, raw = (torch.from_numpy(inp[k]) for k in ("z", "rays_dir", "raw"))
+    dists = zo.sample_dists(z, torch.linalg.vector_norm(d, dim=-1, keepdim=True))
+    want = zo.composite(raw, z, dists, True, torch.from_numpy(noise) * 0.7)
+    got = zest_hip.composite(G(inp["raw"]), G(inp["z"]), G(inp["rays_dir"]), noise=G(noise),
+                             noise_std=0.7, white_bkgd=True)
+    for n, g, w in zip(("rgb_map", "disp_map", "acc_map", "weights", "depth_map", "alpha"), got, want):
+        close(g, w.numpy(), name=n)
+    assert (got[3] >= 0).all() and (got[3].sum(-1) <= 1 + 1e-5).all()
+    w = zest_hip.composite(G(inp["raw"]), G(inp["z"]), G(inp["rays_dir"]))[3].cpu().numpy()   # no noise
+    assert (w >= 0).all() and (w.sum(-1) <= 1 + 1e-5).all()
+    assert np.abs(w[1]).max() == 0.0                       # sigma <= 0 everywhere
+    assert abs(w[2, 0] - 1.0) < 1e-6 and np.abs(w[2, 1:]).max() < 1e-9   # opaque first sample
+
+
+def test_blend(hip):
+    import zest_hip
+    inp, gold = gc.build("blend"), gc.load_golden("blend")
+    r = zest_hip.composite_blend(G(inp["raw_dy"]), G(inp["raw_st"]), G(inp["blend"]), G(inp["z"]),
+                                 G(inp["rays_dir"]))
+    for n, v in zip(("rgb_map", "depth_map", "rgb_map_fg", "depth_map_fg", "weights_fg", "weights_dy"), r):
+        close(v, gold[n], name=n)
+    close(r[6], gold["weights_dy"].sum(-1), name="weights_dd_sum")
+
+
+@pytest.mark.parametrize("case", ["embed3x10", "embed4x10", "embed3x4"])
+def test_embed(hip, case):
+    import zest_hip
+    inp, gold = gc.build(case), gc.load_golden(case)
+    y = zest_hip.embed(G(inp["x"]), gc.CASES[case]["L"])
+    close(y, gold["y"], atol=2e-6, rtol=0, name=case)      # encoder itself is held to 2e-6
+
+
+def test_embed_large_arguments(hip):
+    import zest_hip
+    x = (gc.zs.rng(3).uniform(-60, 60, size=(4096, 3))).astype(np.float32)
+    y = zest_hip.embed(G(x), 10).cpu().numpy()
+    x64 = x.astype(np.float64)
+    for k in range(10):
+        assert np.abs(y[:, 3 + 6 * k:6 + 6 * k] - np.sin(x64 * 2 ** k)).max() < 3e-7
+        assert np.abs(y[:, 6 + 6 * k:9 + 6 * k] - np.cos(x64 * 2 ** k)).max() < 3e-7
+
+
+def test_volume_lookup(hip):
+    import zest_hip
+    inp, gold = gc.build("volume"), gc.load_golden("volume")
+    vcl = zest_hip.volume_to_cl(G(inp["volume"]))
+    assert torch.equal(vcl, G(inp["volume"])[0].permute(1, 2, 3, 0).contiguous())
+    close(zest_hip.volume_lookup(vcl, G(inp["ndc"])[0]), gold["feat"], name="volume")
+
+
+def test_color_lookup(hip):
+    import zest_hip
+    inp, gold = gc.build("color"), gc.load_golden("color")
+    icl = zest_hip.images_to_cl(G(inp["imgs"]))
+    got = zest_hip.color_lookup(icl, G(inp["w2cs"])[0], G(inp["intrinsics"])[0], G(inp["pts"])[0])
+    close(got, gold["colors"], name="colors")
+    m = got.cpu().numpy()[..., 3::4]
+    assert set(np.unique(m)) <= {0.0, 1.0}
+
+
+def _mlp_setup(case):
+    import zest_hip
+    inp = gc.build(case)
+    head = zest_hip.HEAD_NONE
+    if inp["sceneflow"] and inp["net_type"] == "v0":
+        head = zest_hip.HEAD_BLEND if inp["static"] else zest_hip.HEAD_DYNAMIC
+    use_feat = inp["use_mvs"] or inp["net_type"] == "v2"
+    desc = zest_hip.MlpDesc(inp["P"], inp["Fd"], gc.PE_DIR, int(use_feat),
+                            2 if inp["net_type"] == "v2" else 0, head)
+    state = {k: G(v) for k, v in inp["state"].items()}
+    return zest_hip, inp, desc, zest_hip.param_table(state, desc)
+
+
+MLP_CASES = [c for c in gc.CASES if gc.CASES[c]["kind"] == "mlp"]
+
+
+@pytest.mark.parametrize("case", MLP_CASES)
+def test_mlp_f32(hip, case):
+    zh, inp, desc, tab = _mlp_setup(case)
+    packed = zh.mlp_pack(desc, zh.PREC_F32, tab)
+    y = zh.mlp_fwd(desc, zh.PREC_F32, packed, G(inp["x"])[0])
+    close(y, gc.load_golden(case)["y"], name=case)
+
+
+@pytest.mark.parametrize("case", MLP_CASES)
+def test_mlp_bf16(hip, case):
+    zh, inp, desc, tab = _mlp_setup(case)
+    packed = zh.mlp_pack(desc, zh.PREC_BF16, tab)
+    y = zh.mlp_fwd(desc, zh.PREC_BF16, packed, G(inp["x"])[0])
+    gold = gc.load_golden(case)["y"]
+    scale = np.abs(gold).max()
+    close(y, gold, atol=3e-2 * scale, rtol=3e-2, name=case)
+
+
+def test_mlp_ragged_batch(hip):
+    """M not a multiple of the 32-sample tile, and M smaller than one tile."""
+    zh, inp, desc, tab = _mlp_setup("mlp_static_mvs20")
+    gold = gc.load_golden("mlp_static_mvs20")["y"]
+    for prec, tol in ((zh.PREC_F32, (ATOL, RTOL)), (zh.PREC_BF16, (3e-2 * np.abs(gold).max(), 3e-2))):
+        packed = zh.mlp_pack(desc, prec, tab)
+        for M in (1, 31, 45):
+            y = zh.mlp_fwd(desc, prec, packed, G(inp["x"])[0, :M])
+            close(y, gold[:M], atol=tol[0], rtol=tol[1], name="M=%d" % M)

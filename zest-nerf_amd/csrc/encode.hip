@@ -1,0 +1,209 @@
+// Standalone per-sample operators: positional encoding, encoding-volume lookup, colour
+// gather, and the assembled MLP input.  These back the module-level API of the reference
+// (Embedding.forward, utils.index_point_feature, utils.build_color_volume, prepare_pts) and
+// the training path, where per-sample tensors must exist in HBM.  The fused inference kernel
+// (fused.hip) uses the same device functions and never materialises these tensors.
+// All four are HBM/L2-bound gathers: one thread per sample, 16/32-byte corner reads from the
+// channels-last copies of the volume and the images.
+#include "zest_sample_ops.cuh"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__global__ void embed_kernel(const float *__restrict__ x, int M, int C, int L,
+                             float *__restrict__ y) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)M * C) return;
+    const int m = (int)(i / C), c = (int)(i % C);
+    const float v = x[i];
+    float *row = y + (size_t)m * C * (2 * L + 1);
+    row[c] = v;
+    float f = 1.0f;
+    for (int k = 0; k < L; k++) {
+        float s, co;
+        zest_sincos(v * f, &s, &co);
+        row[C * (1 + 2 * k) + c] = s;
+        row[C * (2 + 2 * k) + c] = co;
+        f *= 2.0f;
+    }
+}
+
+__global__ void volume_to_cl_kernel(const float *__restrict__ vol, long long nvox,
+                                    float4 *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nvox) return;
+    float c[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) c[k] = vol[(size_t)k * nvox + i];   // coalesced per channel
+    out[2 * i] = make_float4(c[0], c[1], c[2], c[3]);
+    out[2 * i + 1] = make_float4(c[4], c[5], c[6], c[7]);
+}
+
+__global__ void images_to_cl_kernel(const float *__restrict__ imgs, int V, long long npix,
+                                    float4 *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)V * npix) return;
+    const long long v = i / npix, p = i % npix;
+    const float *b = imgs + (size_t)v * 3 * npix + p;
+    out[i] = make_float4(b[0], b[npix], b[2 * npix], 0.0f);
+}
+
+__global__ void volume_lookup_kernel(const float4 *__restrict__ vol, int D, int H, int W,
+                                     const float *__restrict__ ndc, int M,
+                                     float4 *__restrict__ out) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    float f[8];
+    zest_volume_trilerp<2>(vol, D, H, W, ndc[3 * m], ndc[3 * m + 1], ndc[3 * m + 2], f);
+    out[2 * m] = make_float4(f[0], f[1], f[2], f[3]);
+    out[2 * m + 1] = make_float4(f[4], f[5], f[6], f[7]);
+}
+
+__global__ void color_lookup_kernel(const float4 *__restrict__ imgs, int V, int H, int W,
+                                    const float *__restrict__ w2cs,
+                                    const float *__restrict__ intr,
+                                    const float *__restrict__ pts, int M,
+                                    float4 *__restrict__ out) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const float px = pts[3 * m], py = pts[3 * m + 1], pz = pts[3 * m + 2];
+    for (int v = 0; v < V; v++) {
+        const ZestCam c = zest_load_cam(w2cs, intr, v);      // wave-uniform: scalar loads
+        out[(size_t)m * V + v] = zest_color_tap(imgs + (size_t)v * H * W, H, W, c, px, py, pz);
+    }
+}
+
+// x[m] = PE10(ndc[,t]) | vol(8) | colours(4V) | PE4(view dir)
+__global__ void encode_kernel(const float *__restrict__ ndc, const float *__restrict__ pts,
+                              const float *__restrict__ rays_dir, int R, int S, int has_time,
+                              float t, const float4 *__restrict__ vol, int D, int Hv, int Wv,
+                              const float4 *__restrict__ imgs, int V, int H, int W,
+                              const float *__restrict__ w2cs, const float *__restrict__ intr,
+                              float *__restrict__ x) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= R * S) return;
+    const int r = m / S;
+    const int C = 3 + has_time;
+    const int P = C * 21, F = vol ? 8 + 4 * V : 0;
+    float *row = x + (size_t)m * (P + F + 27);
+    float p[4] = {ndc[3 * m], ndc[3 * m + 1], ndc[3 * m + 2], t};
+    for (int c = 0; c < C; c++) {
+        row[c] = p[c];
+        float f = 1.0f;
+        for (int k = 0; k < 10; k++) {
+            float s, co;
+            zest_sincos(p[c] * f, &s, &co);
+            row[C * (1 + 2 * k) + c] = s;
+            row[C * (2 + 2 * k) + c] = co;
+            f *= 2.0f;
+        }
+    }
+    if (vol) {
+        float f8[8];
+        zest_volume_trilerp<2>(vol, D, Hv, Wv, p[0], p[1], p[2], f8);
+#pragma unroll
+        for (int i = 0; i < 8; i++) row[P + i] = f8[i];
+        const float px = pts[3 * m], py = pts[3 * m + 1], pz = pts[3 * m + 2];
+        for (int v = 0; v < V; v++) {
+            const ZestCam c = zest_load_cam(w2cs, intr, v);
+            const float4 o = zest_color_tap(imgs + (size_t)v * H * W, H, W, c, px, py, pz);
+            float *d = row + P + 8 + 4 * v;
+            d[0] = o.x, d[1] = o.y, d[2] = o.z, d[3] = o.w;
+        }
+    }
+    float dv[3];
+    zest_view_dir(rays_dir + 3 * r, w2cs, dv);
+    float *dr = row + P + F;
+    for (int c = 0; c < 3; c++) {
+        dr[c] = dv[c];
+        float f = 1.0f;
+        for (int k = 0; k < 4; k++) {
+            float s, co;
+            zest_sincos(dv[c] * f, &s, &co);
+            dr[3 * (1 + 2 * k) + c] = s;
+            dr[3 * (2 + 2 * k) + c] = co;
+            f *= 2.0f;
+        }
+    }
+}
+
+inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+extern "C" int zest_embed_fwd(const float *x, int M, int C, int L, float *y, void *stream) {
+    ZEST_CHECK_ARG(x && y, "zest_embed_fwd: null pointer");
+    ZEST_CHECK_ARG(M >= 0 && C >= 1 && L >= 0 && L <= 16, "zest_embed_fwd: bad shape M=%d C=%d L=%d",
+                   M, C, L);
+    if (M == 0) return 0;
+    const long long n = (long long)M * C;
+    hipLaunchKernelGGL(embed_kernel, dim3(zest_div_up(n, kThreads)), dim3(kThreads), 0,
+                       (hipStream_t)stream, x, M, C, L, y);
+    ZEST_RETURN_LAUNCH("zest_embed_fwd");
+}
+
+extern "C" int zest_volume_to_cl(const float *vol, int D, int H, int W, float *vol_cl,
+                                 void *stream) {
+    ZEST_CHECK_ARG(vol && vol_cl && aligned16(vol_cl), "zest_volume_to_cl: bad pointer");
+    ZEST_CHECK_ARG(D >= 1 && H >= 1 && W >= 1, "zest_volume_to_cl: bad shape");
+    const long long n = (long long)D * H * W;
+    hipLaunchKernelGGL(volume_to_cl_kernel, dim3(zest_div_up(n, kThreads)), dim3(kThreads), 0,
+                       (hipStream_t)stream, vol, n, (float4 *)vol_cl);
+    ZEST_RETURN_LAUNCH("zest_volume_to_cl");
+}
+
+extern "C" int zest_images_to_cl(const float *imgs, int V, int H, int W, float *imgs_cl,
+                                 void *stream) {
+    ZEST_CHECK_ARG(imgs && imgs_cl && aligned16(imgs_cl), "zest_images_to_cl: bad pointer");
+    ZEST_CHECK_ARG(V >= 1 && H >= 1 && W >= 1, "zest_images_to_cl: bad shape");
+    const long long n = (long long)V * H * W;
+    hipLaunchKernelGGL(images_to_cl_kernel, dim3(zest_div_up(n, kThreads)), dim3(kThreads), 0,
+                       (hipStream_t)stream, imgs, V, (long long)H * W, (float4 *)imgs_cl);
+    ZEST_RETURN_LAUNCH("zest_images_to_cl");
+}
+
+extern "C" int zest_volume_lookup_fwd(const float *vol_cl, int D, int H, int W, const float *ndc,
+                                      int M, float *out, void *stream) {
+    ZEST_CHECK_ARG(vol_cl && ndc && out && aligned16(vol_cl) && aligned16(out),
+                   "zest_volume_lookup_fwd: bad pointer");
+    ZEST_CHECK_ARG(D >= 1 && H >= 1 && W >= 1 && M >= 0, "zest_volume_lookup_fwd: bad shape");
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(volume_lookup_kernel, dim3(zest_div_up(M, kThreads)), dim3(kThreads), 0,
+                       (hipStream_t)stream, (const float4 *)vol_cl, D, H, W, ndc, M, (float4 *)out);
+    ZEST_RETURN_LAUNCH("zest_volume_lookup_fwd");
+}
+
+extern "C" int zest_color_lookup_fwd(const float *imgs_cl, int V, int H, int W, const float *w2cs,
+                                     const float *intrinsics, const float *pts, int M, float *out,
+                                     void *stream) {
+    ZEST_CHECK_ARG(imgs_cl && w2cs && intrinsics && pts && out && aligned16(imgs_cl) &&
+                       aligned16(out), "zest_color_lookup_fwd: bad pointer");
+    ZEST_CHECK_ARG(V >= 1 && H >= 2 && W >= 2 && M >= 0, "zest_color_lookup_fwd: bad shape");
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(color_lookup_kernel, dim3(zest_div_up(M, kThreads)), dim3(kThreads), 0,
+                       (hipStream_t)stream, (const float4 *)imgs_cl, V, H, W, w2cs, intrinsics, pts,
+                       M, (float4 *)out);
+    ZEST_RETURN_LAUNCH("zest_color_lookup_fwd");
+}
+
+extern "C" int zest_encode_fwd(const float *ndc, const float *pts, const float *rays_dir, int R,
+                               int S, int has_time, float t, const float *vol_cl, int D, int Hv,
+                               int Wv, const float *imgs_cl, int V, int H, int W,
+                               const float *w2cs, const float *intrinsics, float *x, void *stream) {
+    ZEST_CHECK_ARG(ndc && rays_dir && x, "zest_encode_fwd: ndc, rays_dir and x are required");
+    ZEST_CHECK_ARG(R >= 0 && S >= 1, "zest_encode_fwd: bad shape R=%d S=%d", R, S);
+    if (vol_cl) {
+        ZEST_CHECK_ARG(imgs_cl && pts && w2cs && intrinsics && aligned16(vol_cl) &&
+                           aligned16(imgs_cl),
+                       "zest_encode_fwd: features need vol_cl, imgs_cl, pts, w2cs, intrinsics");
+        ZEST_CHECK_ARG(D >= 1 && Hv >= 1 && Wv >= 1 && V >= 1 && H >= 2 && W >= 2,
+                       "zest_encode_fwd: bad volume/image shape");
+    }
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(encode_kernel, dim3(zest_div_up((long long)R * S, kThreads)), dim3(kThreads),
+                       0, (hipStream_t)stream, ndc, pts, rays_dir, R, S, has_time ? 1 : 0, t,
+                       (const float4 *)vol_cl, D, Hv, Wv, (const float4 *)imgs_cl, V, H, W, w2cs,
+                       intrinsics, x);
+    ZEST_RETURN_LAUNCH("zest_encode_fwd");
+}

@@ -1,0 +1,78 @@
+// Host-side plan of the width-256 NeRF MLP as the MFMA kernels execute it.
+//
+// The network (reference networks.py:150-221) is a fixed sequence of 12 "ops", each a
+// Linear producing NJB row-blocks of 32 output features:
+//   0..7  trunk layers  h = relu((W h + b) (*|+) m),  m = pts_bias(feats) recomputed per tile
+//   8     head tile     rows: alpha, then w | sf(6) prob(2)      (on the trunk output)
+//   9     feature_linear (no activation)
+//   10    views_linears.0 on [feature | PE(dir)], relu
+//   11    rgb_linear
+// Work is done transposed, Y^T = W X^T: samples sit on the MFMA column/lane axis and the
+// output features of a 32x32 tile in its accumulator registers, so a tile's activations
+// feed the next op's B operand without leaving the lane.
+//
+// Operands are sequences of SLOTS.  A slot holds one value per lane, i.e. two features:
+// feature(slot, half) for the lane halves 0-31 / 32-63, which both own sample lane&31.
+// A TILE is 1 KiB of packed weights covering SPT slots (8 for bf16 = one 32x32x16 MFMA,
+// 4 for f32 = four 32x32x2 MFMAs): lane l, element e holds
+//   W[row0 + (l & 31)][col(feature(tile*SPT + e, l >> 5))]     (0 outside the matrix).
+// The stream is laid out in consumption order: for op, for row-block jb:
+// [modulation tiles over the feature operand] then one run of tiles per operand segment.
+// Biases live in a separate area: one 128-byte block per (op, jb) holding the accumulator
+// initialiser [half][16] = bias[32 jb + (i&3) + 8 (i>>2) + 4 half]; the eight modulation
+// blocks come first.
+#pragma once
+#include <stdint.h>
+#include <vector>
+#include "../../include/zest_render.h"
+
+namespace zest {
+
+constexpr int kW = 256;            // trunk width (every shipped config: netwidth = 256)
+constexpr int kNumOps = 12;
+constexpr int kMaxSeg = 2;
+
+// slot-order conventions for operands that are produced from accumulator tiles
+enum SlotOrder {
+    ORDER_ACC = 0,      // slot 16T+i <-> feature 32T + (i&3) + 8(i>>2) + 4h   (register engine)
+    ORDER_NATURAL = 1,  // tile of 4 slots over features k0..k0+7: slot j <-> k0 + 4h + j
+};
+
+enum SegKind { SEG_PTS = 0, SEG_FEAT = 1, SEG_VIEWS = 2, SEG_H = 3 };
+
+struct SegPlan {
+    int kind;      // SegKind: which operand the tiles multiply
+    int ntiles;    // tiles in this segment
+};
+
+struct OpPlan {
+    int njb;                 // row blocks of 32 outputs
+    int nseg;
+    SegPlan seg[kMaxSeg];
+    int mod;                 // 1: modulated trunk layer
+    int relu;                // 1: relu in the epilogue
+    int tile_base;           // first tile of the op in the stream
+    int tiles_per_jb;        // including modulation tiles
+    int bias_block;          // first bias block (128 B units)
+};
+
+struct MlpPlan {
+    zest_mlp_desc desc;
+    int precision, order;
+    int spt;                       // slots per tile
+    int ns_pts, ns_feat, ns_views; // padded slot counts of the encoder operands
+    int nt_pts, nt_feat, nt_views, nt_h, nt_h128;
+    int n_tiles, n_bias_blocks;
+    size_t bias_bytes, bytes;      // bias area (padded to 1 KiB) and total
+    OpPlan op[kNumOps];
+    // feature index (column within the operand's own input range) per slot and half; -1 = pad
+    std::vector<int16_t> map_pts, map_feat, map_views;     // [ns][2]
+    // gather tables for the packer: per packed weight element / bias float, source
+    // (param_slot << 24 | element offset), 0xFFFFFFFF = zero
+    std::vector<uint32_t> tile_src, bias_src;
+};
+
+// Builds the plan; returns false (with *err set) for shapes the kernels do not cover.
+bool build_plan(const zest_mlp_desc &d, int precision, int order, MlpPlan *out, const char **err);
+
+}  // namespace zest

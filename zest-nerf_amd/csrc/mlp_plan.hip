@@ -1,0 +1,186 @@
+// Host-only: builds the MLP execution plan and the packer's gather tables (see mlp_plan.h).
+#include "mlp_plan.h"
+#include <string.h>
+
+namespace zest {
+
+namespace {
+
+inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// positional encoding of C coordinates with L bands, reference column order
+// [x(C), sin(2^0 x)(C), cos(2^0 x)(C), sin(2^1 x)(C), ...] (networks.py:60-65)
+void pe_map_acc(int C, int L, int ns, std::vector<int16_t> &m) {
+    m.assign((size_t)ns * 2, -1);
+    for (int q = 0; q < L * C; q++) {
+        const int band = q / C, coord = q % C;
+        m[2 * q] = (int16_t)(C + 2 * C * band + coord);           // half 0: sin
+        m[2 * q + 1] = (int16_t)(C + 2 * C * band + C + coord);   // half 1: cos
+    }
+    for (int p = 0; p < (C + 1) / 2; p++) {                       // raw coordinates, two per slot
+        const int q = L * C + p;
+        m[2 * q] = (int16_t)(2 * p);
+        m[2 * q + 1] = (int16_t)(2 * p + 1 < C ? 2 * p + 1 : -1);
+    }
+}
+
+void feat_map_acc(int V, int ns, std::vector<int16_t> &m) {
+    m.assign((size_t)ns * 2, -1);
+    for (int q = 0; q < 4; q++) m[2 * q] = (int16_t)q, m[2 * q + 1] = (int16_t)(q + 4);
+    for (int p = 0; p < (V + 1) / 2; p++)
+        for (int c = 0; c < 4; c++) {
+            const int q = 4 + 4 * p + c;
+            m[2 * q] = (int16_t)(8 + 8 * p + c);
+            m[2 * q + 1] = (int16_t)(2 * p + 1 < V ? 8 + 8 * p + 4 + c : -1);
+        }
+}
+
+void natural_map(int width, int spt, int ntiles, std::vector<int16_t> &m) {
+    m.assign((size_t)ntiles * spt * 2, -1);
+    for (int t = 0; t < ntiles; t++)
+        for (int j = 0; j < spt; j++)
+            for (int h = 0; h < 2; h++) {
+                const int f = t * 2 * spt + spt * h + j;
+                m[2 * (t * spt + j) + h] = (int16_t)(f < width ? f : -1);
+            }
+}
+
+inline int h_feature(int order, int spt, int slot, int half) {
+    if (order == ORDER_ACC) {
+        const int T = slot / 16, i = slot % 16;
+        return 32 * T + (i & 3) + 8 * (i >> 2) + 4 * half;
+    }
+    const int t = slot / spt, j = slot % spt;
+    return t * 2 * spt + spt * half + j;
+}
+
+struct RowSrc { int param, row; };       // param < 0: zero row
+
+}  // namespace
+
+bool build_plan(const zest_mlp_desc &d, int precision, int order, MlpPlan *P, const char **err) {
+    static const char *e_prec = "precision must be ZEST_PREC_F32 or ZEST_PREC_BF16";
+    static const char *e_pts = "in_ch_pts must be 63 (xyz, L=10) or 84 (xyzt, L=10)";
+    static const char *e_views = "in_ch_views must be 27 (L=4)";
+    static const char *e_feat = "in_ch_feat must be 8 + 4V with 1 <= V <= 16 when use_feat is set";
+    static const char *e_head = "bad head / net_type combination";
+    if (precision != ZEST_PREC_F32 && precision != ZEST_PREC_BF16) return *err = e_prec, false;
+    if (d.in_ch_pts != 63 && d.in_ch_pts != 84) return *err = e_pts, false;
+    if (d.in_ch_views != 27) return *err = e_views, false;
+    const int F = d.use_feat ? d.in_ch_feat : 0;
+    if (d.use_feat && (F < 12 || (F - 8) % 4 != 0 || F > 72)) return *err = e_feat, false;
+    if (d.head < 0 || d.head > 2 || (d.net_type != 0 && d.net_type != 2) ||
+        (d.net_type == 2 && (d.head != 0 || !d.use_feat)))
+        return *err = e_head, false;
+
+    MlpPlan &p = *P;
+    p.desc = d, p.precision = precision, p.order = order;
+    p.spt = precision == ZEST_PREC_BF16 ? 8 : 4;
+    const int spt = p.spt, C = d.in_ch_pts == 63 ? 3 : 4, V = d.use_feat ? (F - 8) / 4 : 0;
+    if (order == ORDER_ACC) {
+        p.ns_pts = round_up(10 * C + (C + 1) / 2, 8);
+        p.ns_views = 16;
+        p.ns_feat = d.use_feat ? round_up(4 + 4 * ((V + 1) / 2), 8) : 0;
+        if (d.use_feat && p.ns_feat < 16) p.ns_feat = 16;      // engine variants: 2 or 3 tiles
+        pe_map_acc(C, 10, p.ns_pts, p.map_pts);
+        pe_map_acc(3, 4, p.ns_views, p.map_views);
+        if (d.use_feat) feat_map_acc(V, p.ns_feat, p.map_feat);
+    } else {
+        p.ns_pts = round_up(d.in_ch_pts, 2 * spt) / 2;
+        p.ns_views = round_up(27, 2 * spt) / 2;
+        p.ns_feat = d.use_feat ? round_up(F, 2 * spt) / 2 : 0;
+        natural_map(d.in_ch_pts, spt, p.ns_pts / spt, p.map_pts);
+        natural_map(27, spt, p.ns_views / spt, p.map_views);
+        if (d.use_feat) natural_map(F, spt, p.ns_feat / spt, p.map_feat);
+    }
+    p.nt_pts = p.ns_pts / spt, p.nt_views = p.ns_views / spt, p.nt_feat = p.ns_feat / spt;
+    p.nt_h = 128 / spt, p.nt_h128 = 64 / spt;
+
+    // ---- op table ----------------------------------------------------------------------
+    int tile = 0, bblk = d.use_feat ? 8 : 0;
+    for (int o = 0; o < kNumOps; o++) {
+        OpPlan &op = p.op[o];
+        memset(&op, 0, sizeof(op));
+        op.njb = 8, op.nseg = 1, op.seg[0] = {SEG_H, p.nt_h};
+        if (o < 8) op.mod = d.use_feat ? 1 : 0, op.relu = 1;
+        if (o == 0) op.seg[0] = {SEG_PTS, p.nt_pts};
+        if (o == 5) op.nseg = 2, op.seg[0] = {SEG_PTS, p.nt_pts}, op.seg[1] = {SEG_H, p.nt_h};
+        if (o == 8) op.njb = 1;
+        if (o == 10) op.njb = 4, op.relu = 1, op.nseg = 2, op.seg[1] = {SEG_VIEWS, p.nt_views};
+        if (o == 11) op.njb = 1, op.seg[0] = {SEG_H, p.nt_h128};
+        op.tiles_per_jb = op.mod ? p.nt_feat : 0;
+        for (int s = 0; s < op.nseg; s++) op.tiles_per_jb += op.seg[s].ntiles;
+        op.tile_base = tile, op.bias_block = bblk;
+        tile += op.njb * op.tiles_per_jb, bblk += op.njb;
+    }
+    p.n_tiles = tile, p.n_bias_blocks = bblk;
+    p.bias_bytes = (size_t)round_up(bblk * 128, 1024);
+    p.bytes = p.bias_bytes + (size_t)tile * 1024;
+
+    // ---- gather tables -------------------------------------------------------------------
+    const int ld[ZEST_P_COUNT] = {d.in_ch_pts, kW, kW, kW, kW, kW + d.in_ch_pts, kW, kW,
+                                  d.in_ch_feat, kW + d.in_ch_views, kW, kW, kW / 2, kW, kW};
+    const uint32_t ZERO = 0xFFFFFFFFu;
+    p.tile_src.assign((size_t)tile * 64 * spt, ZERO);
+    p.bias_src.assign(p.bias_bytes / 4, ZERO);
+
+    auto row_src = [&](int o, int row) -> RowSrc {
+        if (o < 8) return {ZEST_P_PTS0 + o, row};
+        if (o == 9) return {ZEST_P_FEATURE, row};
+        if (o == 10) return {row < kW / 2 ? ZEST_P_VIEWS : -1, row};
+        if (o == 11) return {row < 3 ? ZEST_P_RGB : -1, row};
+        // head tile: row 0 alpha, then the extra heads in output order
+        if (row == 0) return {ZEST_P_ALPHA, 0};
+        if (d.head == ZEST_HEAD_BLEND && row == 1) return {ZEST_P_HEAD0, 0};
+        if (d.head == ZEST_HEAD_DYNAMIC && row >= 1 && row <= 6) return {ZEST_P_HEAD0, row - 1};
+        if (d.head == ZEST_HEAD_DYNAMIC && row >= 7 && row <= 8) return {ZEST_P_HEAD1, row - 7};
+        return {-1, 0};
+    };
+    auto emit_tiles = [&](int &t, int param_of_rows_op, int jb, const SegPlan &sg, int col0,
+                          bool is_mod) {
+        for (int k = 0; k < sg.ntiles; k++, t++)
+            for (int l = 0; l < 64; l++)
+                for (int e = 0; e < spt; e++) {
+                    const int slot = k * spt + e, half = l >> 5, row = 32 * jb + (l & 31);
+                    int feat;
+                    switch (sg.kind) {
+                        case SEG_PTS: feat = p.map_pts[2 * slot + half]; break;
+                        case SEG_FEAT: feat = p.map_feat[2 * slot + half]; break;
+                        case SEG_VIEWS: feat = p.map_views[2 * slot + half]; break;
+                        default: feat = h_feature(order, spt, slot, half);
+                    }
+                    RowSrc rs = is_mod ? RowSrc{ZEST_P_PTS_BIAS, row} : row_src(param_of_rows_op, row);
+                    if (feat < 0 || rs.param < 0) continue;
+                    p.tile_src[((size_t)t * 64 + l) * spt + e] =
+                        ((uint32_t)rs.param << 24) | (uint32_t)(rs.row * ld[rs.param] + col0 + feat);
+                }
+    };
+    auto emit_bias = [&](int block, int o, int jb, bool is_mod) {
+        for (int h = 0; h < 2; h++)
+            for (int i = 0; i < 16; i++) {
+                const int row = 32 * jb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                RowSrc rs = is_mod ? RowSrc{ZEST_P_PTS_BIAS, row} : row_src(o, row);
+                if (rs.param < 0) continue;
+                p.bias_src[(size_t)block * 32 + h * 16 + i] = ((uint32_t)rs.param << 24) | rs.row;
+            }
+    };
+    if (d.use_feat)
+        for (int jb = 0; jb < 8; jb++) emit_bias(jb, 0, jb, true);
+    for (int o = 0; o < kNumOps; o++) {
+        const OpPlan &op = p.op[o];
+        int t = op.tile_base;
+        for (int jb = 0; jb < op.njb; jb++) {
+            emit_bias(op.bias_block + jb, o, jb, false);
+            if (op.mod) emit_tiles(t, o, jb, SegPlan{SEG_FEAT, p.nt_feat}, 0, true);
+            int col0 = 0;
+            for (int s = 0; s < op.nseg; s++) {
+                emit_tiles(t, o, jb, op.seg[s], col0, false);
+                // width of the operand just consumed, in the Linear's own column order
+                col0 += op.seg[s].kind == SEG_PTS ? d.in_ch_pts : kW;
+            }
+        }
+    }
+    return true;
+}
+
+}  // namespace zest

@@ -1,0 +1,292 @@
+"""ctypes binding of libzest_hip.so (include/zest_render.h) for torch tensors.
+
+The library is the product: if it is missing or a call fails this module raises — there
+is no PyTorch or CPU fallback anywhere in the package.  Tensors cross the boundary as raw
+device pointers (`Tensor.data_ptr()`), sizes, and the current HIP stream handle; outputs
+are allocated here through torch's caching allocator (the reference allocates every
+output fresh as well, renderer.py:64, utils.py:480).
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzest_hip.so")
+
+PREC_F32, PREC_BF16 = 0, 1
+HEAD_NONE, HEAD_BLEND, HEAD_DYNAMIC = 0, 1, 2
+P_COUNT = 15
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+
+class MlpDesc(C.Structure):
+    _fields_ = [("in_ch_pts", C.c_int32), ("in_ch_feat", C.c_int32), ("in_ch_views", C.c_int32),
+                ("use_feat", C.c_int32), ("net_type", C.c_int32), ("head", C.c_int32)]
+
+    @property
+    def in_ch(self):
+        return self.in_ch_pts + (self.in_ch_feat if self.use_feat else 0) + self.in_ch_views
+
+    @property
+    def out_ch(self):
+        return {HEAD_NONE: 4, HEAD_BLEND: 5, HEAD_DYNAMIC: 12}[self.head]
+
+
+class ViewSet(C.Structure):
+    _fields_ = [("vol_cl", _vp), ("D", C.c_int32), ("Hv", C.c_int32), ("Wv", C.c_int32),
+                ("imgs_cl", _vp), ("V", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("w2cs", _vp), ("intrinsics", _vp)]
+
+
+_SIGS = {
+    "zest_abi_version": (_i, []),
+    "zest_last_error": (C.c_char_p, []),
+    "zest_device_info": (_i, [C.POINTER(_i), C.POINTER(_i), C.c_char_p, _sz]),
+    "zest_composite_fwd": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "zest_composite_blend_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i,
+                                      _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "zest_weighted_complement_sum": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "zest_embed_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "zest_volume_to_cl": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "zest_images_to_cl": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "zest_volume_lookup_fwd": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "zest_color_lookup_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "zest_encode_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp, _i, _i, _i, _vp, _i, _i, _i,
+                             _vp, _vp, _vp, _vp]),
+    "zest_mlp_packed_bytes": (_sz, [C.POINTER(MlpDesc), _i]),
+    "zest_mlp_pack": (_i, [C.POINTER(MlpDesc), _i, C.POINTER(_vp), _vp, _vp]),
+    "zest_mlp_fwd": (_i, [C.POINTER(MlpDesc), _i, _vp, _vp, _i, _vp, _vp]),
+    "zest_render_fused_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, C.POINTER(MlpDesc), _vp,
+                                   C.POINTER(ViewSet), C.POINTER(MlpDesc), _vp, C.POINTER(ViewSet),
+                                   _f, _i, _i, _vp, _vp]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Names include/zest_render.h declares (used by the CPU symbol test)."""
+    return list(_SIGS)
+
+
+def lib():
+    """Load the shared library once; raise if it is absent (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s not found: build it with `python %s/build_hip.py` "
+                               "(zest-nerf_amd has no non-HIP execution path)" % (LIB_PATH, _HERE))
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)           # AttributeError if the header and library disagree
+            fn.restype, fn.argtypes = res, args
+        if L.zest_abi_version() != 1:
+            raise RuntimeError("libzest_hip.so ABI %d != 1" % L.zest_abi_version())
+        _lib = L
+    return _lib
+
+
+def _check(code, what):
+    if code != 0:
+        msg = lib().zest_last_error().decode(errors="replace")
+        raise RuntimeError("%s failed (hipError %d): %s" % (what, code, msg))
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _dev(t, name):
+    """Normalise to a contiguous fp32 device tensor; reject CPU tensors loudly."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("zest_hip: %s is on %s; this path runs only on a HIP device" % (name, t.device))
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+# ------------------------------------------------------------------------ compositing
+def composite(raw, z, rays_dir, noise=None, noise_std=0.0, white_bkgd=False, want_disp=True):
+    """raw [R,S,4], z [R,S], rays_dir [R,3] -> rgb_map, disp, acc, weights, depth, alpha."""
+    raw, z, rays_dir, noise = _dev(raw, "raw"), _dev(z, "z"), _dev(rays_dir, "rays_dir"), _dev(noise, "noise")
+    R, S = z.shape
+    o = lambda *s: torch.empty(*s, device=z.device, dtype=torch.float32)
+    rgb, depth, acc, disp, w, a = o(R, 3), o(R), o(R), o(R), o(R, S), o(R, S)
+    _check(lib().zest_composite_fwd(_ptr(raw), _ptr(z), _ptr(rays_dir), _ptr(noise), float(noise_std),
+                                    int(bool(white_bkgd)), R, S, _ptr(rgb), _ptr(depth), _ptr(acc),
+                                    _ptr(disp), _ptr(w), _ptr(a), _stream(z)), "zest_composite_fwd")
+    return rgb, disp, acc, w, depth, a
+
+
+def composite_blend(raw_dy, raw_st, blend, z, rays_dir, noise=None, noise_std=0.0):
+    raw_dy, raw_st, blend = _dev(raw_dy, "raw_dy"), _dev(raw_st, "raw_st"), _dev(blend, "blend")
+    z, rays_dir, noise = _dev(z, "z"), _dev(rays_dir, "rays_dir"), _dev(noise, "noise")
+    R, S = z.shape
+    o = lambda *s: torch.empty(*s, device=z.device, dtype=torch.float32)
+    rgb, depth, rgb_fg, depth_fg, w_fg, w_dy, dd = o(R, 3), o(R), o(R, 3), o(R), o(R, S), o(R, S), o(R)
+    _check(lib().zest_composite_blend_fwd(_ptr(raw_dy), _ptr(raw_st), _ptr(blend), _ptr(z),
+                                          _ptr(rays_dir), _ptr(noise), float(noise_std), R, S,
+                                          _ptr(rgb), _ptr(depth), _ptr(rgb_fg), _ptr(depth_fg),
+                                          _ptr(w_fg), _ptr(w_dy), _ptr(dd), _stream(z)),
+           "zest_composite_blend_fwd")
+    return rgb, depth, rgb_fg, depth_fg, w_fg, w_dy, dd
+
+
+def weighted_complement_sum(w, p):
+    w, p = _dev(w, "w"), _dev(p, "p")
+    R, S = w.shape
+    out = torch.empty(R, device=w.device, dtype=torch.float32)
+    _check(lib().zest_weighted_complement_sum(_ptr(w), _ptr(p), R, S, _ptr(out), _stream(w)),
+           "zest_weighted_complement_sum")
+    return out
+
+
+# --------------------------------------------------------------------- per-sample operators
+def embed(x, n_freqs):
+    x = _dev(x, "x")
+    Cn = x.shape[-1]
+    M = x.numel() // Cn
+    y = torch.empty(*x.shape[:-1], Cn * (2 * n_freqs + 1), device=x.device, dtype=torch.float32)
+    _check(lib().zest_embed_fwd(_ptr(x), M, Cn, n_freqs, _ptr(y), _stream(x)), "zest_embed_fwd")
+    return y
+
+
+def volume_to_cl(vol):
+    """[1,8,D,H,W] or [8,D,H,W] -> channels-last [D,H,W,8]."""
+    vol = _dev(vol, "volume")
+    if vol.dim() == 5:
+        if vol.shape[0] != 1:
+            raise RuntimeError("zest_hip: volume batch must be 1, got %d" % vol.shape[0])
+        vol = vol[0]
+    if vol.shape[0] != 8:
+        raise RuntimeError("zest_hip: encoding volume must have 8 channels, got %d" % vol.shape[0])
+    _, D, H, W = vol.shape
+    out = torch.empty(D, H, W, 8, device=vol.device, dtype=torch.float32)
+    _check(lib().zest_volume_to_cl(_ptr(vol), D, H, W, _ptr(out), _stream(vol)), "zest_volume_to_cl")
+    return out
+
+
+def images_to_cl(imgs):
+    """[1,V,3,H,W] or [V,3,H,W] -> [V,H,W,4]."""
+    imgs = _dev(imgs, "imgs")
+    if imgs.dim() == 5:
+        if imgs.shape[0] != 1:
+            raise RuntimeError("zest_hip: image batch must be 1, got %d" % imgs.shape[0])
+        imgs = imgs[0]
+    V, c, H, W = imgs.shape
+    if c != 3:
+        raise RuntimeError("zest_hip: images must have 3 channels, got %d" % c)
+    out = torch.empty(V, H, W, 4, device=imgs.device, dtype=torch.float32)
+    _check(lib().zest_images_to_cl(_ptr(imgs), V, H, W, _ptr(out), _stream(imgs)), "zest_images_to_cl")
+    return out
+
+
+def volume_lookup(vol_cl, ndc):
+    ndc = _dev(ndc, "ndc")
+    D, H, W, _ = vol_cl.shape
+    M = ndc.numel() // 3
+    out = torch.empty(*ndc.shape[:-1], 8, device=ndc.device, dtype=torch.float32)
+    _check(lib().zest_volume_lookup_fwd(_ptr(vol_cl), D, H, W, _ptr(ndc), M, _ptr(out), _stream(ndc)),
+           "zest_volume_lookup_fwd")
+    return out
+
+
+def color_lookup(imgs_cl, w2cs, intrinsics, pts):
+    pts, w2cs, intrinsics = _dev(pts, "pts"), _dev(w2cs, "w2cs"), _dev(intrinsics, "intrinsics")
+    V, H, W, _ = imgs_cl.shape
+    if w2cs.shape[-3] < V or intrinsics.shape[-3] < V:
+        raise RuntimeError("zest_hip: %d views but only %d poses" % (V, w2cs.shape[-3]))
+    M = pts.numel() // 3
+    out = torch.empty(*pts.shape[:-1], 4 * V, device=pts.device, dtype=torch.float32)
+    _check(lib().zest_color_lookup_fwd(_ptr(imgs_cl), V, H, W, _ptr(w2cs), _ptr(intrinsics), _ptr(pts),
+                                       M, _ptr(out), _stream(pts)), "zest_color_lookup_fwd")
+    return out
+
+
+def encode(ndc, pts, rays_dir, t=None, vol_cl=None, imgs_cl=None, w2cs=None, intrinsics=None):
+    """ndc, pts [R,S,3]; rays_dir [R,3] -> x [R,S,C_in] (reference prepare_pts layout)."""
+    ndc, pts, rays_dir = _dev(ndc, "ndc"), _dev(pts, "pts"), _dev(rays_dir, "rays_dir")
+    w2cs, intrinsics = _dev(w2cs, "w2cs"), _dev(intrinsics, "intrinsics")
+    R, S, _ = ndc.shape
+    has_t = t is not None
+    D = Hv = Wv = V = H = W = 0
+    if vol_cl is not None:
+        D, Hv, Wv, _ = vol_cl.shape
+        V, H, W, _ = imgs_cl.shape
+        if w2cs is None or w2cs.shape[-3] < V:
+            raise RuntimeError("zest_hip: encode needs one pose per source view")
+    c_in = (4 if has_t else 3) * 21 + (8 + 4 * V if vol_cl is not None else 0) + 27
+    x = torch.empty(R, S, c_in, device=ndc.device, dtype=torch.float32)
+    _check(lib().zest_encode_fwd(_ptr(ndc), _ptr(pts), _ptr(rays_dir), R, S, int(has_t),
+                                 float(t) if has_t else 0.0, _ptr(vol_cl), D, Hv, Wv, _ptr(imgs_cl),
+                                 V, H, W, _ptr(w2cs), _ptr(intrinsics), _ptr(x), _stream(ndc)),
+           "zest_encode_fwd")
+    return x
+
+
+# ----------------------------------------------------------------------------------- MLP
+def mlp_packed_bytes(desc, precision):
+    return int(lib().zest_mlp_packed_bytes(C.byref(desc), int(precision)))
+
+
+def mlp_pack(desc, precision, params):
+    """params: list of 2*P_COUNT tensors-or-None (weight, bias per ZEST_P_* slot)."""
+    dev = next(p for p in params if p is not None).device
+    keep = [(_dev(p, "param") if p is not None else None) for p in params]
+    arr = (_vp * (2 * P_COUNT))(*[_ptr(p) for p in keep])
+    nbytes = mlp_packed_bytes(desc, precision)
+    packed = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    _check(lib().zest_mlp_pack(C.byref(desc), int(precision), arr, _ptr(packed),
+                               torch.cuda.current_stream(dev).cuda_stream), "zest_mlp_pack")
+    return packed
+
+
+def mlp_fwd(desc, precision, packed, x):
+    x = _dev(x, "x")
+    if x.shape[-1] != desc.in_ch:
+        raise RuntimeError("zest_hip: MLP expects %d input channels, got %d" % (desc.in_ch, x.shape[-1]))
+    M = x.numel() // x.shape[-1]
+    out = torch.empty(*x.shape[:-1], desc.out_ch, device=x.device, dtype=torch.float32)
+    _check(lib().zest_mlp_fwd(C.byref(desc), int(precision), _ptr(packed), _ptr(x), M, _ptr(out),
+                              _stream(x)), "zest_mlp_fwd")
+    return out
+
+
+def device_info():
+    cu, khz = _i(0), _i(0)
+    name = C.create_string_buffer(64)
+    _check(lib().zest_device_info(C.byref(cu), C.byref(khz), name, 64), "zest_device_info")
+    return dict(cu_count=cu.value, clock_khz=khz.value, arch=name.value.decode())
+
+
+# --------------------------------------------------------------- state dict -> parameter table
+_PARAM_SLOTS = [("pts_linears.%d" % i, i) for i in range(8)] + [
+    ("pts_bias", 8), ("views_linears.0", 9), ("feature_linear", 10), ("alpha_linear", 11),
+    ("rgb_linear", 12)]
+
+
+def param_table(state, desc, prefix="nerf."):
+    """Order the nn.Linear tensors of a reference-layout state dict as zest_mlp_pack expects."""
+    tab = [None] * (2 * P_COUNT)
+
+    def put(slot, name):
+        tab[2 * slot] = state[prefix + name + ".weight"]
+        tab[2 * slot + 1] = state[prefix + name + ".bias"]
+    for name, slot in _PARAM_SLOTS:
+        if name == "pts_bias" and not desc.use_feat:
+            continue
+        put(slot, name)
+    if desc.head == HEAD_BLEND:
+        put(13, "w_linear")
+    elif desc.head == HEAD_DYNAMIC:
+        put(13, "sf_linear")
+        put(14, "prob_linear")
+    return tab

@@ -45,6 +45,7 @@ def test_composite(hip, case):
 def test_composite_noise_and_properties(hip):
     import zest_hip
     inp = gc.composite_inputs(101, R=37, S=150, dead_ray=True)     # ragged: 150 = 2*64 + 22
+    inp["raw"][2, :, 3] = 1e5                                       # opaque at the first sample
     noise = gc.zs.rng(5).standard_normal((37, 150)).astype(np.float32)
     from oracle import zest_oracle as zo
     z, d, raw = (torch.from_numpy(inp[k]) for k in ("z", "rays_dir", "raw"))

@@ -1,0 +1,251 @@
+"""Drop-in `renderer` module: ZeST-NeRF volume rendering on MI355X (HIP kernels).
+
+`rendering` keeps the reference's signature and return-dict keys
+(/root/reference/renderer.py:579-626); so do the helpers other reference modules import
+(`raw2outputs`, `raw2outputs_blending`, `raw2alpha`, `depth2dist`, `compute_2d_prob`).
+All device work goes through the C ABI (include/zest_render.h); there is no PyTorch
+restatement in this package.  Gradients are not provided yet: calls made with autograd
+recording raise (backward kernels are SURVEY.md 8(f) next-2).
+
+Two execution plans:
+  * complete  - per-sample tensors in HBM (encode -> MLP -> composite kernels); returns
+                every key of the reference dict.  Used for train-mode calls.
+  * fused     - one launch, per-ray maps only (zest_render_fused_fwd); chosen for
+                inference-shaped calls when `args.zest_maps_only` is set (the whole-image
+                loops in the generators set it: they read 2 / 7 per-ray maps only,
+                reference networks.py:697-704, train.py:898-899).
+"""
+import torch
+
+import zest_hip
+from networks import MVSNeRF, resolve_precision
+from utils import images_channels_last, volume_channels_last
+
+__all__ = ["rendering", "raw2outputs", "raw2outputs_blending", "raw2alpha", "depth2dist",
+           "compute_2d_prob"]
+
+
+def _draw_noise(shape, device):
+    """Density noise ~ N(0,1); one draw per compositing call that uses it, like the reference
+    (renderer.py:140,189).  Tests replace this hook to inject known noise."""
+    return torch.randn(shape, device=device)
+
+
+def _no_grad_only(*tensors):
+    if torch.is_grad_enabled() and any(t is not None and torch.is_tensor(t) and t.requires_grad
+                                       for t in tensors):
+        raise NotImplementedError("zest renderer: backward kernels are not built yet "
+                                  "(SURVEY.md 8(f) next-2); call under torch.no_grad()")
+
+
+# ------------------------------------------------------------------ reference helper surface
+def compute_2d_prob(weights_p_mix, raw_prob_ref2p):
+    """sum_s w * (1 - prob)  (reference renderer.py:22-32)."""
+    lead = weights_p_mix.shape[:-1]
+    S = weights_p_mix.shape[-1]
+    out = zest_hip.weighted_complement_sum(weights_p_mix.reshape(-1, S), raw_prob_ref2p.reshape(-1, S))
+    return out.view(*lead)
+
+
+def depth2dist(z_vals, cos_angle):
+    """Sample spacing along the ray, last = 1e10, scaled by |dir| (reference renderer.py:74-89).
+    Kept for API parity; the compositing kernels recompute this from z and rays_dir."""
+    d = z_vals[..., 1:] - z_vals[..., :-1]
+    d = torch.cat([d, torch.full_like(z_vals[..., :1], 1e10)], -1)
+    return d * cos_angle
+
+
+def _split_dists(z_vals, dists):
+    """The kernels take (z, |dir|); recover |dir| from the caller's dists = dz * |dir|."""
+    z = z_vals.reshape(-1, z_vals.shape[-1])
+    d = dists.reshape(-1, dists.shape[-1])
+    norm = d[:, -1:] / 1e10
+    pseudo_dir = torch.cat([torch.zeros_like(norm), torch.zeros_like(norm), norm], -1)
+    return z, pseudo_dir
+
+
+def raw2alpha(sigma, dist):
+    """alpha = 1 - exp(-sigma*dist), weights = alpha * exclusive-prod(1 - alpha + 1e-10)
+    (reference renderer.py:91-113).  Runs the compositing kernel on depths rebuilt from the
+    spacings; sigma < 0 is clamped to 0, which every reference caller has already done."""
+    _no_grad_only(sigma, dist)
+    lead, S = sigma.shape[:-1], sigma.shape[-1]
+    d = dist.reshape(-1, S).float()
+    norm = d[:, -1:] / 1e10
+    z = torch.cumsum(torch.cat([torch.zeros_like(norm), d[:, :-1] / norm], -1), -1)
+    raw = torch.zeros(d.shape[0], S, 4, device=d.device)
+    raw[..., 3] = sigma.reshape(-1, S)
+    pdir = torch.cat([torch.zeros_like(norm), torch.zeros_like(norm), norm], -1)
+    _, _, _, w, _, a = zest_hip.composite(raw, z, pdir)
+    return a.view(*lead, S), w.view(*lead, S)
+
+
+def raw2outputs(raw, z_vals, dists, white_bkgd=False, raw_noise_std=0):
+    """[N,R,S,4] -> rgb_map, disp_map, acc_map, weights, depth_map, alpha
+    (reference renderer.py:115-164)."""
+    _no_grad_only(raw)
+    lead, S = z_vals.shape[:-1], z_vals.shape[-1]
+    z, pdir = _split_dists(z_vals, dists)
+    noise = _draw_noise(z_vals.shape, z_vals.device).reshape(-1, S) if raw_noise_std > 0 else None
+    rgb, disp, acc, w, depth, a = zest_hip.composite(raw.reshape(-1, S, 4), z, pdir, noise,
+                                                     float(raw_noise_std), bool(white_bkgd))
+    return (rgb.view(*lead, 3), disp.view(*lead), acc.view(*lead), w.view(*lead, S),
+            depth.view(*lead), a.view(*lead, S))
+
+
+def raw2outputs_blending(raw_dy, raw_rigid, raw_blend_w, z_vals, dists, raw_noise_std=0):
+    """-> rgb_map, depth_map, rgb_map_fg, depth_map_fg, weights_fg, weights_dy
+    (reference renderer.py:166-219)."""
+    _no_grad_only(raw_dy, raw_rigid, raw_blend_w)
+    lead, S = z_vals.shape[:-1], z_vals.shape[-1]
+    z, pdir = _split_dists(z_vals, dists)
+    noise = _draw_noise(z_vals.shape, z_vals.device).reshape(-1, S) if raw_noise_std > 0 else None
+    rgb, depth, rgb_fg, depth_fg, w_fg, w_dy, _ = zest_hip.composite_blend(
+        raw_dy.reshape(-1, S, 4), raw_rigid.reshape(-1, S, 4), raw_blend_w.reshape(-1, S), z, pdir,
+        noise, float(raw_noise_std))
+    return (rgb.view(*lead, 3), depth.view(*lead), rgb_fg.view(*lead, 3), depth_fg.view(*lead),
+            w_fg.view(*lead, S), w_dy.view(*lead, S))
+
+
+# ------------------------------------------------------------------------------ view sets
+class _Views:
+    """Volume + source images + cameras of one feature lookup, in kernel layout."""
+
+    def __init__(self, volume, imgs, cam_mat):
+        self.vol_cl = self.imgs_cl = self.w2cs = self.intr = None
+        if cam_mat is not None:
+            self.w2cs = cam_mat['w2cs'][0].float().contiguous()
+            self.intr = cam_mat['intrinsics'][0].float().contiguous()
+        if volume is not None:
+            if not torch.is_tensor(volume):
+                raise NotImplementedError("zest renderer: callable volumes are not supported")
+            if imgs is None or cam_mat is None:
+                raise RuntimeError("zest renderer: a feature volume needs source images and cameras")
+            self.vol_cl = volume_channels_last(volume)
+            self.imgs_cl = images_channels_last(imgs)
+
+    def encode(self, ndc, pts, rays_dir, t=None):
+        return zest_hip.encode(ndc, pts, rays_dir, t, self.vol_cl, self.imgs_cl, self.w2cs, self.intr)
+
+
+def _check_embedders(embedding_pts, embedding_dir, in_channels):
+    for e, c, L, what in ((embedding_pts, in_channels, 10, "points"), (embedding_dir, 3, 4, "directions")):
+        if e is None or getattr(e, "N_freqs", None) != L or getattr(e, "in_channels", None) != c:
+            raise NotImplementedError(
+                "zest renderer: the HIP encoder implements the shipped embedders only "
+                "(%s: in_channels=%d, N_freqs=%d)" % (what, c, L))
+
+
+def _net(network_fn, what):
+    if not isinstance(network_fn, MVSNeRF):
+        raise TypeError("zest renderer: %s must be a zest networks.MVSNeRF (got %s)" %
+                        (what, type(network_fn).__name__))
+    return network_fn
+
+
+# ------------------------------------------------------------------------------- rendering
+def rendering(args, rays_pts, rays_ndc, depth_candidates, rays_dir,
+              volume_feature_static=None, volume_feature_dynamic=None,
+              imgs=None, img_feat=None, neighbour_frames=None,
+              im_cam_mat=None, nb_cam_mat=None,
+              network_fn=None, network_fn_dy=None,
+              embedding_pts=None, embedding_xyzt=None, embedding_dir=None,
+              chain_bwd=False, chain_5frames=False, ref_frame_idx=None, num_frames=None,
+              time_codes=None, white_bkgd=False, scene_flow=False, val=False,
+              raw_noise_std=0):
+    """Volume-render a batch of rays; same arguments and result keys as the reference
+    (renderer.py:579-626).  rays_pts/rays_ndc [1,R,S,3], depth_candidates [1,R,S],
+    rays_dir [1,R,3]."""
+    if time_codes is not None:
+        raise NotImplementedError("zest renderer: time codes (Neural3D video mode) are out of scope")
+    if img_feat is not None:
+        raise NotImplementedError("zest renderer: img_feat is always None in the reference callers")
+    if getattr(args, "use_color_volume", False):
+        raise NotImplementedError("zest renderer: use_color_volume is never set by the reference configs")
+    if rays_ndc.shape[0] != 1:
+        raise RuntimeError("zest renderer: image batch must be 1 (reference train.py:307)")
+    _no_grad_only(rays_pts, rays_ndc, depth_candidates, rays_dir, volume_feature_static,
+                  volume_feature_dynamic)
+    net_s = _net(network_fn, "network_fn")
+    _check_embedders(embedding_pts, embedding_dir, 3)
+    prec = resolve_precision(args)
+    N, R, S, _ = rays_ndc.shape
+    ndc, pts = rays_ndc[0].float().contiguous(), rays_pts[0].float().contiguous()
+    z, dirs = depth_candidates[0].float().contiguous(), rays_dir[0].float().contiguous()
+    if torch.is_grad_enabled() and any(p.requires_grad for p in net_s.parameters()):
+        raise NotImplementedError("zest renderer: backward kernels are not built yet "
+                                  "(SURVEY.md 8(f) next-2); call under torch.no_grad()")
+
+    def mlp(net, x):
+        return zest_hip.mlp_fwd(net.desc(), prec, net.packed(prec), x)
+
+    def noise():
+        return _draw_noise((1, R, S), ndc.device)[0] if raw_noise_std > 0 else None
+
+    # ---- static NeRF (reference render_static, renderer.py:322-373)
+    vs = _Views(volume_feature_static, imgs, im_cam_mat)
+    x_s = vs.encode(ndc, pts, dirs)
+    raw_s = mlp(net_s, x_s)
+    raw_rgba = raw_s[..., :4]
+    blend = raw_s[..., 4] if scene_flow else None
+    rgb_map, _, _, weights, depth_map, alpha = zest_hip.composite(
+        raw_rgba, z, dirs, noise(), float(raw_noise_std), bool(white_bkgd))
+    F = net_s.in_ch_feat if vs.vol_cl is not None else 0
+    input_feat = x_s[None, ..., 63:63 + F] if F else None
+    ret = {'rgb_map': rgb_map[None], 'depth_map': depth_map[None], 'raw_rgba': raw_rgba[None],
+           'input_feat': input_feat, 'weights': weights[None],
+           'raw_blend_w': blend[None] if blend is not None else None, 'alpha': alpha[None]}
+    if not scene_flow:
+        return ret
+
+    # ---- dynamic NeRF (reference render_dynamic, renderer.py:378-575)
+    net_d = _net(network_fn_dy, "network_fn_dy")
+    _check_embedders(embedding_xyzt, embedding_dir, 4)
+    vd = _Views(volume_feature_dynamic, neighbour_frames, nb_cam_mat)
+
+    def dyn_pass(ndc3, t):
+        return mlp(net_d, vd.encode(ndc3, pts, dirs, float(t)))
+
+    raw_ref = dyn_pass(ndc, ref_frame_idx)
+    sf_prev, sf_post = raw_ref[..., 4:7], raw_ref[..., 7:10]
+    prob_prev, prob_post = raw_ref[..., 10], raw_ref[..., 11]
+    rgb_ref, depth_ref, rgb_fg, depth_fg, w_fg, w_dd, dd_sum = zest_hip.composite_blend(
+        raw_ref[..., :4], raw_rgba, blend, z, dirs, noise(), float(raw_noise_std))
+    ret.update({'rgb_map_ref': rgb_ref[None], 'depth_map_ref': depth_ref[None],
+                'rgb_map_ref_dy': rgb_fg[None], 'depth_map_ref_dy': depth_fg[None],
+                'weights_map_dd': dd_sum[None]})
+    if val:
+        return ret
+    ret.update({'raw_sf_ref2prev': sf_prev[None], 'raw_sf_ref2post': sf_post[None],
+                'raw_pts_ref': rays_ndc[..., :3], 'weights_ref_dy': w_fg[None],
+                'raw_blend_w': blend[None], 'raw_prob_ref2prev': prob_prev[None],
+                'raw_prob_ref2post': prob_post[None]})
+    # Neighbour frames.  Reference quirk kept on purpose (renderer.py:478-479, 505-506,
+    # 541-543, 570-572): raw_noise_std is passed in the white_bkgd position, so these renders
+    # composite onto white whenever raw_noise_std != 0 and never receive density noise.
+    white_nb = bool(raw_noise_std)
+    step = 1. / num_frames * 2.
+
+    def nb_render(raw):
+        rgb, _, _, w, _, _ = zest_hip.composite(raw[..., :4], z, dirs, None, 0.0, white_nb)
+        return rgb, w
+
+    ndc_prev = ndc + sf_prev
+    raw_prev = dyn_pass(ndc_prev, ref_frame_idx - step)
+    rgb_prev, w_prev = nb_render(raw_prev)
+    ndc_post = ndc + sf_post
+    raw_post = dyn_pass(ndc_post, ref_frame_idx + step)
+    rgb_post, w_post = nb_render(raw_post)
+    ret.update({'raw_pts_prev': ndc_prev[None], 'raw_sf_prev2ref': raw_prev[None, ..., 7:10],
+                'rgb_map_prev_dy': rgb_prev[None], 'raw_pts_post': ndc_post[None],
+                'raw_sf_post2ref': raw_post[None, ..., 4:7], 'rgb_map_post_dy': rgb_post[None],
+                'prob_map_prev': zest_hip.weighted_complement_sum(w_prev, prob_prev)[None],
+                'prob_map_post': zest_hip.weighted_complement_sum(w_post, prob_post)[None]})
+    if chain_bwd:
+        ndc_pp, t_pp = ndc_prev + raw_prev[..., 4:7], ref_frame_idx - 2. / num_frames * 2.
+    else:
+        ndc_pp, t_pp = ndc_post + raw_post[..., 7:10], ref_frame_idx + 2. / num_frames * 2.
+    ret['raw_pts_pp'] = ndc_pp[None]
+    if chain_5frames:
+        ret['rgb_map_pp_dy'] = nb_render(dyn_pass(ndc_pp, t_pp))[0][None]
+    return ret

@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Throughput of the ZeST-NeRF rendering hot path on MI355X: rendered rays/s.
+
+    python bench.py [--gpus N --steps K --warmup W] [--workload NAME]
+
+A step is one `renderer.rendering(...)` call (the drop-in boundary) over one batch of
+synthetic rays through the fused HIP renderer, inputs resident in HBM.  Default workload
+(BASELINE.json configs[1]): NSFF Balloon1 geometry, 1024 rays x 128 samples, static MLP,
+bf16 MFMA.  With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank
+renders its own 1024-ray shard and the rendered pixels are all-gathered over RCCL inside the
+timed step (weak scaling: per-GPU work fixed).
+
+Prints ONE JSON line: metric/value/unit..., plus
+  roofline:     MFMA bound for the fused kernel - algorithmic MLP FLOPs per launch / average
+                kernel time from HIP events on the launch stream, against 2.5 PFLOP/s
+                (dense bf16, /opt/skills/guides/MI355X_MICROARCH.md)
+  cpu_baseline: the CPU oracle (oracle/zest_oracle.py: the reference's op sequence in
+                PyTorch-CPU fp32) timed on this box's host cores on a bounded sample of the
+                same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "zest-nerf_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+
+WORKLOADS = {
+    # name: rays, samples, static volume+views, dynamic net, dyn volume
+    "nsff_static_1024x128": dict(R=1024, S=128, use_mvs=False, scene_flow=False,
+                                 note="BASELINE configs[1], use_mvs off (SURVEY 8(d) reading): C_in=90"),
+    "nsff_static_mvs_1024x128": dict(R=1024, S=128, use_mvs=True, scene_flow=False,
+                                     note="configs[1] with the K=8 encoding volume: C_in=130"),
+    "nsff_zest_val_1024x128": dict(R=1024, S=128, use_mvs=True, scene_flow=True,
+                                   note="BASELINE configs[2], inference: static + dynamic nets"),
+    "zest_val_4096x192": dict(R=4096, S=192, use_mvs=True, scene_flow=True,
+                              note="BASELINE configs[3] shape on one GPU"),
+}
+
+
+def build_workload(name, seed, device, rays=None):
+    import networks
+    import zest_synth as zs
+    w = dict(WORKLOADS[name])
+    R = rays or w["R"]
+    sc = zs.make_scene(seed, R, w["S"], H=288, W=512, V=8, V_dy=4, pad=24, vol_depth=128, focal=400.0,
+                       static_volume=w["use_mvs"], dynamic=w["scene_flow"])
+    feat_dim = 8 + 4 * 8
+    sf = w["scene_flow"]
+
+    def net(P, Fd, static, use_mvs, sd):
+        m = networks.MVSNeRF(D=8, W=256, input_ch_pts=P, output_ch=4, input_ch_views=27,
+                             input_ch_feat=Fd, skips=[4], net_type="v0", sceneflow=sf, static=static,
+                             use_mvs=use_mvs)
+        lay = zs.mlp_layout(P, 27, Fd, sf, static, use_mvs)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in zs.fill_mlp_state(lay, sd).items()})
+        return m.to(device)
+
+    G = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    d = SimpleNamespace(name=name, R=R, S=w["S"], cfg=w, sc=sc)
+    d.net_s = net(63, feat_dim, True, w["use_mvs"], seed + 1)
+    d.net_d = net(84, 24, False, True, seed + 2) if sf else None
+    d.args = SimpleNamespace(netchunk=1024, feat_dim=feat_dim, feat_dim_dy=24, img_downscale=1.0,
+                             use_color_volume=False, net_type="v0", precision=16, zest_maps_only=True)
+    d.emb = (networks.Embedding(3, 10), networks.Embedding(4, 10), networks.Embedding(3, 4))
+    d.t = {k: G(sc[k]) for k in ("rays_pts", "rays_ndc", "depth_candidates", "rays_dir")}
+    d.cam = {"w2cs": G(sc["w2cs"]), "intrinsics": G(sc["intrinsics"])}
+    d.vol_s = G(sc["vol_static"]) if w["use_mvs"] else None
+    d.imgs = G(sc["imgs"]) if w["use_mvs"] else None
+    d.vol_d = G(sc["vol_dynamic"]) if sf else None
+    d.nb_imgs = G(sc["nb_imgs"]) if sf else None
+    d.nb_cam = {"w2cs": G(sc["nb_w2cs"]), "intrinsics": G(sc["nb_intrinsics"])} if sf else None
+    return d
+
+
+def render_step(d):
+    import renderer
+    return renderer.rendering(
+        d.args, d.t["rays_pts"], d.t["rays_ndc"], d.t["depth_candidates"], d.t["rays_dir"],
+        volume_feature_static=d.vol_s, volume_feature_dynamic=d.vol_d, imgs=d.imgs,
+        neighbour_frames=d.nb_imgs, im_cam_mat=d.cam, nb_cam_mat=d.nb_cam, network_fn=d.net_s,
+        network_fn_dy=d.net_d, embedding_pts=d.emb[0], embedding_xyzt=d.emb[1], embedding_dir=d.emb[2],
+        ref_frame_idx=0.1, num_frames=24, scene_flow=d.cfg["scene_flow"], val=True)
+
+
+def flops_per_ray_batch(d):
+    """Algorithmic MLP FLOPs of one step: 2 * sum(in*out) per sample."""
+    from oracle import zest_oracle as zo
+    sf = d.cfg["scene_flow"]
+    f = zo.mlp_flops_per_sample(zo.MlpSpec(63, 27, 40, sf, True, d.cfg["use_mvs"]))
+    if sf:
+        f += zo.mlp_flops_per_sample(zo.MlpSpec(84, 27, 24, True, False, True))
+    return f * d.R * d.S, f
+
+
+def cpu_baseline(d, budget_s=15.0):
+    """Oracle (reference op sequence, PyTorch-CPU fp32, all host cores) on the first rays of the
+    same workload; bounded to ~budget_s seconds."""
+    from oracle import zest_oracle as zo
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sc, sf = d.sc, d.cfg["scene_flow"]
+    Rc = min(d.R, 256)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    st = lambda net: {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    ns = zo.Net(st(d.net_s), zo.MlpSpec(63, 27, 40, sf, True, d.cfg["use_mvs"]))
+    nd = zo.Net(st(d.net_d), zo.MlpSpec(84, 27, 24, True, False, True)) if sf else None
+    cams = (T(sc["w2cs"])[0], T(sc["intrinsics"])[0])
+    nb = (T(sc["nb_w2cs"])[0], T(sc["nb_intrinsics"])[0]) if sf else None
+    kw = dict(vol_static=T(sc["vol_static"])[0] if d.cfg["use_mvs"] else None,
+              vol_dynamic=T(sc["vol_dynamic"])[0] if sf else None,
+              imgs=T(sc["imgs"])[0] if d.cfg["use_mvs"] else None,
+              nb_imgs=T(sc["nb_imgs"])[0] if sf else None, cams=cams, nb_cams=nb, scene_flow=sf,
+              val=True, ref_frame_idx=0.1, num_frames=24, explicit=False)
+    a = [T(sc[k])[0, :Rc] for k in ("rays_pts", "rays_ndc", "depth_candidates", "rays_dir")]
+    # the GPU box gives one GPU's job a 16-core share of the host; more threads only thrash
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(max(1, min(16, ncpu)))
+    with torch.no_grad():
+        zo.rendering(*a, ns, nd, **kw)                       # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            zo.rendering(*a, ns, nd, **kw)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or n >= 200:
+                break
+    return {"value": Rc * n / el, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d calls of %d rays x %d samples of the same workload (oracle, torch-CPU fp32, "
+                      "grid_sample/linear/cumprod op sequence of the reference)" % (n, Rc, d.S)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="nsff_static_1024x128", choices=list(WORKLOADS))
+    ap.add_argument("--rays", type=int, default=None, help="rays per GPU (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the rendering path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if a.gpus != world and rank == 0:
+        print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (a.gpus, world), file=sys.stderr)
+
+    import zest_hip
+    zest_hip.lib()
+    d = build_workload(a.workload, 1234 + rank, dev, a.rays)
+    gathered = torch.empty(world * d.R, 16, device=dev) if world > 1 else None
+
+    def step():
+        ret = render_step(d)
+        if world > 1:       # all-gather of the rendered pixels over RCCL/xGMI
+            dist.all_gather_into_tensor(gathered, ret["zest_packed_maps"])
+        return ret
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(a.warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        fence()
+        el = time.perf_counter() - t0
+        # per-launch kernel time from HIP events on the launch stream (outside the timed region)
+        evs = []
+        for _ in range(min(a.steps, 50)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            render_step(d)
+            e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        k_ms = float(np.mean([x.elapsed_time(y) for x, y in evs]))
+    tmax = torch.tensor([el], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    el = float(tmax.item())
+    if rank == 0:
+        flops, fps = flops_per_ray_batch(d)
+        ach = flops / (k_ms * 1e-3) / 1e12
+        out = {
+            "metric": "rendered rays/sec (1024-ray x 128-sample batch)", "value": world * d.R * a.steps / el,
+            "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": a.workload, "rays_per_gpu": d.R, "samples_per_ray": d.S,
+                       "note": d.cfg["note"], "path": "renderer.rendering -> zest_render_fused_fwd",
+                       "collective": "all_gather(rendered pixels)" if world > 1 else "none"},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                         "kernel": "fused_render_kernel", "kernel_ms": k_ms, "flop_per_sample": fps},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(d, a.cpu_budget)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -145,9 +145,9 @@ int zest_mlp_fwd(const zest_mlp_desc *desc, int precision, const void *packed,
                  const float *x, int M, float *out, void *stream);
 
 /* ---- fused inference path ---------------------------------------------------------
- * One launch for rendering(..., val=True) (reference renderer.py:579-626 with the
- * early return at :444-445): encode + feature gathers + static MLP [+ dynamic MLP]
- * + compositing, nothing per-sample written to HBM.
+ * rendering(..., val=True) (reference renderer.py:579-626 with the early return at
+ * :444-445) in two launches: encode + feature gathers + static MLP [+ dynamic MLP] +
+ * per-block compositing (nothing per-sample written to HBM), then a per-ray combine.
  * out [R,16]: 0-2 rgb_map, 3 depth_map, 4 acc_map; with the dynamic net also
  * 5-7 rgb_map_ref, 8 depth_map_ref, 9-11 rgb_map_ref_dy, 12 depth_map_ref_dy,
  * 13 weights_map_dd; 14,15 reserved. */
@@ -160,13 +160,18 @@ typedef struct zest_view_set {
     const float *intrinsics;  /* [>=V,3,3]           */
 } zest_view_set;
 
+/* bytes of caller-owned scratch zest_render_fused_fwd needs for R rays of S samples
+ * (one 80-byte record per 32-sample block) */
+size_t zest_render_fused_workspace(int R, int S);
+
 int zest_render_fused_fwd(const float *ndc, const float *pts, const float *z,
                           const float *rays_dir, int R, int S,
                           const zest_mlp_desc *desc_static, const void *packed_static,
                           const zest_view_set *views_static,
                           const zest_mlp_desc *desc_dynamic, const void *packed_dynamic,
                           const zest_view_set *views_dynamic, float frame_idx,
-                          int precision, int white_bkgd, float *out, void *stream);
+                          int precision, int white_bkgd, void *workspace, float *out,
+                          void *stream);
 
 #ifdef __cplusplus
 }

@@ -37,14 +37,15 @@ def build_nets(sc):
     return ns.to("cuda:0"), nd
 
 
-def call_rendering(case, precision=32, monkeypatch=None):
+def call_rendering(case, precision=32, monkeypatch=None, maps_only=False):
     import networks
     import renderer
     c, sc = gc.CASES[case], gc.build(case)
     sf = sc["scene_flow"]
     ns, nd = build_nets(sc)
     args = SimpleNamespace(netchunk=1024, feat_dim=sc["feat_dim"], feat_dim_dy=24, img_downscale=1.0,
-                           use_color_volume=False, net_type="v0", precision=precision)
+                           use_color_volume=False, net_type="v0", precision=precision,
+                           zest_maps_only=maps_only)
     cam = {"w2cs": G(sc["w2cs"]), "intrinsics": G(sc["intrinsics"])}
     dy = sf and sc["use_mvs_dy"]
     nb_cam = {"w2cs": G(sc["nb_w2cs"]), "intrinsics": G(sc["nb_intrinsics"])} if dy else None
@@ -93,6 +94,26 @@ def test_rendering_bf16_mode(hip, case, monkeypatch):
     for k in ("depth_map", "depth_map_ref"):
         if k in gold:
             close(ret[k][0], gold[k], atol=6e-2, rtol=0, name=k)
+
+
+FUSED_CASES = ["render_static_mvs", "render_static_nomvs", "render_static_white", "render_zest_val",
+               "render_zest_nomvsdy"]
+
+
+@pytest.mark.parametrize("case", FUSED_CASES)
+def test_fused_renderer(hip, case):
+    """The one-launch inference path (bf16 engine, nothing per-sample in HBM): equal to the
+    per-op bf16 path to fp32 rounding (same engine, same operand rounding), and within the
+    bf16 tolerance of the reference's golden maps."""
+    fused = call_rendering(case, 16, maps_only=True)
+    perop = call_rendering(case, 16)
+    gold = gc.load_golden(case)
+    keys = [k for k in fused if k not in ("acc_map", "zest_packed_maps")]
+    assert set(keys) == {k for k in ("rgb_map", "depth_map", "rgb_map_ref", "depth_map_ref",
+                                     "rgb_map_ref_dy", "depth_map_ref_dy", "weights_map_dd") if k in gold}
+    for k in keys:
+        close(fused[k][0], perop[k][0].cpu().numpy(), atol=2e-5, rtol=1e-4, name="fused~perop/" + k)
+        close(fused[k][0], gold[k], atol=6e-2 if "depth" in k else 2e-2, rtol=0, name="fused~ref/" + k)
 
 
 def test_module_api(hip):

@@ -13,7 +13,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libzest_hip.so")
 SOURCES = ["capi.hip", "composite.hip", "encode.hip", "mlp_plan.hip", "mlp.hip", "mlp_bf16.hip",
-           "fused.hip"]
+           "fused.hip", "fused_s0.hip", "fused_s2.hip", "fused_s3.hip", "fused_s0d0.hip",
+           "fused_s3d2.hip", "fused_s2d2.hip", "fused_s2d0.hip", "fused_s3d0.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
@@ -52,7 +53,7 @@ def build(force=False, extra_flags=()):
             o = os.path.join(OBJ, s.replace(".hip", ".o"))
             if os.path.exists(o):
                 os.remove(o)
-    with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
+    with ThreadPoolExecutor(max_workers=min(7, len(srcs))) as ex:
         objs = list(ex.map(lambda s: _compile(s, list(extra_flags)), srcs))
     if _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs

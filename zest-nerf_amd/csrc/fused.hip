@@ -1,10 +1,153 @@
-// Fused inference renderer (placeholder entry point until the kernel lands this round).
-#include "zest_common.cuh"
+// zest_render_fused_fwd: argument checks and dispatch to the fused renderer variants
+// (fused.cuh).  Before any launch the shapes the kernel indexes with are validated on the
+// host: a bad pointer or size here must never reach the GPU.
+#include <string.h>
+#include "fused.cuh"
+#include "mlp_plan.h"
 
-extern "C" int zest_render_fused_fwd(const float *, const float *, const float *, const float *, int,
-                                     int, const zest_mlp_desc *, const void *, const zest_view_set *,
-                                     const zest_mlp_desc *, const void *, const zest_view_set *, float,
-                                     int, int, float *, void *) {
-    zest_set_error("zest_render_fused_fwd: not implemented yet");
-    return (int)hipErrorNotSupported;
+namespace zest {
+
+// Chain the block records of each ray: out += T * sums, T *= exit transmittance.
+__global__ void fused_combine_kernel(const float *__restrict__ partials, int R, int bpr, int dyn,
+                                     int white_bkgd, float *__restrict__ out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    float Ts = 1.f, Tb = 1.f, Tf = 1.f;
+    float s[5] = {0, 0, 0, 0, 0}, bl[5] = {0, 0, 0, 0, 0}, fg[4] = {0, 0, 0, 0};
+    for (int b = 0; b < bpr; b++) {
+        const float *p = partials + ((size_t)r * bpr + b) * kPartialFloats;
+#pragma unroll
+        for (int i = 0; i < 5; i++) s[i] += Ts * p[1 + i];
+        Ts *= p[0];
+        if (dyn) {
+#pragma unroll
+            for (int i = 0; i < 5; i++) bl[i] += Tb * p[7 + i];
+            Tb *= p[6];
+#pragma unroll
+            for (int i = 0; i < 4; i++) fg[i] += Tf * p[13 + i];
+            Tf *= p[12];
+        }
+    }
+    float4 *o = reinterpret_cast<float4 *>(out + (size_t)r * 16);
+    const float bg = white_bkgd ? 1.0f - s[4] : 0.0f;
+    o[0] = make_float4(s[0] + bg, s[1] + bg, s[2] + bg, s[3]);
+    o[1] = make_float4(s[4], bl[0], bl[1], bl[2]);
+    o[2] = make_float4(bl[3], fg[0], fg[1], fg[2]);
+    o[3] = make_float4(fg[3], bl[4], 0.f, 0.f);
+}
+
+}  // namespace zest
+
+namespace {
+
+bool fill_net(const zest_mlp_desc *d, const void *packed, const zest_view_set *vs, int pts_ch,
+              zest::FusedNet *n, int *nt_feat, int *units, const char **err) {
+    memset(n, 0, sizeof(*n));
+    if (!d || !packed) return *err = "descriptor and packed weights are required", false;
+    if (d->in_ch_pts != pts_ch) return *err = "unexpected in_ch_pts for this slot", false;
+    zest::MlpPlan plan;
+    if (!zest::build_plan(*d, ZEST_PREC_BF16, zest::ORDER_ACC, &plan, err)) return false;
+    n->bias = (const float *)packed;
+    n->tiles = (const uint4 *)((const char *)packed + plan.bias_bytes);
+    n->head = d->head, n->v2 = d->net_type == 2;
+    *nt_feat = d->use_feat ? plan.nt_feat : 0;
+    *units = plan.n_tiles;
+    if (((uintptr_t)packed & 15) != 0) return *err = "packed weights must be 16-byte aligned", false;
+    if (vs) {
+        n->w2cs = vs->w2cs, n->intr = vs->intrinsics;
+        n->vol = (const float4 *)vs->vol_cl, n->imgs = (const float4 *)vs->imgs_cl;
+        n->D = vs->D, n->Hv = vs->Hv, n->Wv = vs->Wv, n->V = vs->V, n->H = vs->H, n->W = vs->W;
+    }
+    if (d->use_feat) {
+        if (!vs || !vs->vol_cl || !vs->imgs_cl || !vs->w2cs || !vs->intrinsics)
+            return *err = "a net with features needs volume, images and cameras", false;
+        if (vs->D < 1 || vs->Hv < 1 || vs->Wv < 1 || vs->H < 2 || vs->W < 2)
+            return *err = "bad volume / image shape", false;
+        if (vs->V < 1 || vs->V > zest::kMaxViews || 8 + 4 * vs->V != d->in_ch_feat)
+            return *err = "view count does not match in_ch_feat = 8 + 4V", false;
+        if (((uintptr_t)vs->vol_cl | (uintptr_t)vs->imgs_cl) & 15)
+            return *err = "volume / images must be 16-byte aligned", false;
+    } else {
+        n->vol = nullptr, n->imgs = nullptr;          // features unused: never dereferenced
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" size_t zest_render_fused_workspace(int R, int S) {
+    if (R <= 0 || S <= 0) return 16;
+    return (size_t)R * ((S + 31) / 32) * zest::kPartialFloats * sizeof(float);
+}
+
+extern "C" int zest_render_fused_fwd(const float *ndc, const float *pts, const float *z,
+                                     const float *rays_dir, int R, int S,
+                                     const zest_mlp_desc *desc_static, const void *packed_static,
+                                     const zest_view_set *views_static,
+                                     const zest_mlp_desc *desc_dynamic, const void *packed_dynamic,
+                                     const zest_view_set *views_dynamic, float frame_idx,
+                                     int precision, int white_bkgd, void *workspace, float *out,
+                                     void *stream) {
+    ZEST_CHECK_ARG(ndc && z && rays_dir && out && workspace,
+                   "zest_render_fused_fwd: ndc, z, rays_dir, workspace, out required");
+    ZEST_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "zest_render_fused_fwd: workspace must be 16-byte aligned");
+    ZEST_CHECK_ARG(R >= 0 && S >= 1, "zest_render_fused_fwd: bad shape R=%d S=%d", R, S);
+    ZEST_CHECK_ARG(precision == ZEST_PREC_BF16,
+                   "zest_render_fused_fwd: the fused renderer is the bf16 engine; use the per-op "
+                   "entry points for fp32");
+    ZEST_CHECK_ARG(((uintptr_t)out & 15) == 0, "zest_render_fused_fwd: out must be 16-byte aligned");
+    zest::FusedArgs a;
+    memset(&a, 0, sizeof(a));
+    a.ndc = ndc, a.pts = pts, a.z = z, a.dir = rays_dir, a.R = R, a.S = S;
+    a.frame_idx = frame_idx, a.white_bkgd = white_bkgd, a.out = out;
+    a.bpr = (S + 31) / 32, a.partials = (float *)workspace;
+    const char *err = nullptr;
+    int nts = 0, ntd = 0, units_s = 0, units_d = 0;
+    ZEST_CHECK_ARG(fill_net(desc_static, packed_static, views_static, 63, &a.st, &nts, &units_s, &err),
+                   "zest_render_fused_fwd: static net: %s", err);
+    const bool dyn = desc_dynamic != nullptr;
+    if (dyn) {
+        ZEST_CHECK_ARG(fill_net(desc_dynamic, packed_dynamic, views_dynamic, 84, &a.dy, &ntd, &units_d, &err),
+                       "zest_render_fused_fwd: dynamic net: %s", err);
+        ZEST_CHECK_ARG(desc_static->head == ZEST_HEAD_BLEND && desc_dynamic->head == ZEST_HEAD_DYNAMIC,
+                       "zest_render_fused_fwd: blending needs a static net with the blend head and "
+                       "a dynamic net with the scene-flow heads");
+    }
+    ZEST_CHECK_ARG(pts || (!a.st.vol && !a.dy.vol), "zest_render_fused_fwd: pts required with features");
+    if (R == 0) return 0;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        cus = 256;
+    const int n_pass = zest_div_up((long long)R * a.bpr, zest::kFusedWaves * zest::kFusedNB);
+    const int blocks = n_pass < cus ? n_pass : cus;                 // one workgroup per CU
+    hipStream_t st = (hipStream_t)stream;
+    const int key = (dyn ? 100 : 0) + nts * 10 + ntd;
+    int rc = -1;
+#define ZEST_CASE(k, tag)                                                                        \
+    case k:                                                                                      \
+        ZEST_CHECK_ARG(zest::fused_units_##tag(0) == units_s && zest::fused_units_##tag(1) == units_d, \
+                       "zest_render_fused_fwd: packed stream is %d+%d units, kernel expects %d+%d",  \
+                       units_s, units_d, zest::fused_units_##tag(0), zest::fused_units_##tag(1));    \
+        rc = zest::fused_launch_##tag(a, blocks, st);                                            \
+        break;
+    switch (key) {
+        ZEST_CASE(0, s0)
+        ZEST_CASE(20, s2)
+        ZEST_CASE(30, s3)
+        ZEST_CASE(100, s0d0)
+        ZEST_CASE(120, s2d0)
+        ZEST_CASE(130, s3d0)
+        ZEST_CASE(122, s2d2)
+        ZEST_CASE(132, s3d2)
+        default:
+            zest_set_error("zest_render_fused_fwd: no fused variant for %d static / %d dynamic feature "
+                           "tiles%s", nts, ntd, dyn ? "" : " (static only)");
+            return (int)hipErrorInvalidValue;
+    }
+#undef ZEST_CASE
+    if (rc != 0) return rc;
+    hipLaunchKernelGGL(zest::fused_combine_kernel, dim3(zest_div_up(R, 128)), dim3(128), 0, st,
+                       a.partials, R, a.bpr, dyn ? 1 : 0, white_bkgd, out);
+    ZEST_RETURN_LAUNCH("zest_render_fused_fwd(combine)");
 }

@@ -19,7 +19,7 @@ using zest::MlpPlan;
 
 struct DevPlan {
     MlpPlan plan;
-    uint32_t *tile_src = nullptr, *bias_src = nullptr;   // device copies of the gather tables
+    uint32_t *tile_src = nullptr, *bias_src = nullptr, *hdr_src = nullptr;   // device gather tables
 };
 
 std::mutex g_mu;
@@ -44,10 +44,13 @@ DevPlan *get_plan(const zest_mlp_desc &d, int precision, int order, bool need_ta
     }
     if (need_tables && !dp->tile_src) {
         const size_t nt = dp->plan.tile_src.size() * 4, nb = dp->plan.bias_src.size() * 4;
+        const size_t nh = dp->plan.hdr_src.size() * 4;
         hipError_t e = hipMalloc(&dp->tile_src, nt);
-        if (e == hipSuccess) e = hipMalloc(&dp->bias_src, nb);
+        if (e == hipSuccess) e = hipMalloc(&dp->bias_src, nb ? nb : 4);
+        if (e == hipSuccess) e = hipMalloc(&dp->hdr_src, nh ? nh : 4);
         if (e == hipSuccess) e = hipMemcpy(dp->tile_src, dp->plan.tile_src.data(), nt, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(dp->bias_src, dp->plan.bias_src.data(), nb, hipMemcpyHostToDevice);
+        if (e == hipSuccess && nb) e = hipMemcpy(dp->bias_src, dp->plan.bias_src.data(), nb, hipMemcpyHostToDevice);
+        if (e == hipSuccess && nh) e = hipMemcpy(dp->hdr_src, dp->plan.hdr_src.data(), nh, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             zest_set_error("zest_mlp_pack: uploading gather tables: %s", hipGetErrorString(e));
             dp->tile_src = nullptr;
@@ -82,6 +85,17 @@ __global__ void pack_kernel(ParamTable pt, const uint32_t *__restrict__ tile_src
         else
             ((float *)w_out)[i] = v;
     }
+}
+
+// header units of the bf16 stream: 64 fp32 (bias block, modulation bias block) at the head
+__global__ void pack_headers_kernel(ParamTable pt, const uint32_t *__restrict__ hdr_src, size_t n,
+                                    char *__restrict__ w_out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = hdr_src[i];
+    if (s == 0xFFFFFFFFu) return;
+    const size_t unit = i / 64, j = i % 64;
+    ((float *)(w_out + unit * 1024))[j] = pt.p[2 * (s >> 24) + 1][s & 0xFFFFFF];
 }
 
 // ------------------------------------------------------------------ fp32 parity kernel
@@ -239,11 +253,15 @@ extern "C" int zest_mlp_pack(const zest_mlp_desc *desc, int precision, const flo
     const size_t n_w = p.tile_src.size(), n_b = p.bias_src.size();
     const size_t n = n_w > n_b ? n_w : n_b;
     void *w_out = (char *)packed + p.bias_bytes;
-    if (precision == ZEST_PREC_BF16)
+    if (precision == ZEST_PREC_BF16) {
         hipLaunchKernelGGL(pack_kernel<true>, dim3(zest_div_up(n, 256)), dim3(256), 0,
                            (hipStream_t)stream, pt, dp->tile_src, n_w, dp->bias_src, n_b,
                            (float *)packed, w_out);
-    else
+        const size_t n_h = p.hdr_src.size();
+        if (n_h)     // same stream, after the bf16 pass that zero-filled the header units
+            hipLaunchKernelGGL(pack_headers_kernel, dim3(zest_div_up(n_h, 256)), dim3(256), 0,
+                               (hipStream_t)stream, pt, dp->hdr_src, n_h, (char *)w_out);
+    } else
         hipLaunchKernelGGL(pack_kernel<false>, dim3(zest_div_up(n, 256)), dim3(256), 0,
                            (hipStream_t)stream, pt, dp->tile_src, n_w, dp->bias_src, n_b,
                            (float *)packed, w_out);
@@ -268,5 +286,5 @@ extern "C" int zest_mlp_fwd(const zest_mlp_desc *desc, int precision, const void
                            (hipStream_t)stream, pr, bias, (const float4 *)tiles, x, M, out);
         ZEST_RETURN_LAUNCH("zest_mlp_fwd(f32)");
     }
-    return zest::mlp_bf16_launch(p, bias, tiles, x, M, out, (hipStream_t)stream);
+    return zest::mlp_bf16_launch(p, tiles, x, M, out, (hipStream_t)stream);
 }

@@ -35,8 +35,7 @@ __device__ __forceinline__ void load_operand(const float *__restrict__ xrow, boo
 
 template <int NB, int NT_PTS, bool MOD, int NT_FEAT>
 __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void mlp_bf16_kernel(
-    SlotMaps maps, const float *__restrict__ bias, const uint4 *__restrict__ tiles,
-    const float *__restrict__ x, int M, int P, int F, int C_in, int C_out, int head, int v2,
+    SlotMaps maps, const uint4 *__restrict__ tiles, const float *__restrict__ x, int M, int P, int F, int C_in, int C_out, int head, int v2,
     float *__restrict__ out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 31, half = lane >> 5;
@@ -55,8 +54,9 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void mlp_bf16_kernel(
         load_operand<2>(xrow + P + F, valid, half, maps.views, views[nb]);
     }
     f32x16 headt[NB], rgbt[NB];
-    GlobalTiles gt{tiles, lane};
-    engine_forward<NB, NT_PTS, MOD, NT_FEAT>(gt, bias, half, v2 != 0, pts, feat, views, headt, rgbt);
+    GlobalTiles gt{(gptr_u4)tiles, lane, half};
+    int unit = 0;
+    engine_forward<NB, NT_PTS, MOD, NT_FEAT>(gt, unit, v2 != 0, pts, feat, views, headt, rgbt);
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) {
         const long long m = m_base + 32 * nb + col;
@@ -81,21 +81,26 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void mlp_bf16_kernel(
 }
 
 template <int NB, int NT_PTS, bool MOD, int NT_FEAT>
-static int launch_one(const MlpPlan &p, const SlotMaps &maps, const float *bias, const void *tiles,
-                      const float *x, int M, float *out, hipStream_t stream) {
+static int launch_one(const MlpPlan &p, const SlotMaps &maps, const void *tiles, const float *x, int M,
+                      float *out, hipStream_t stream) {
+    if (p.n_tiles != stream_units(NT_PTS, MOD ? NT_FEAT : 0)) {
+        zest_set_error("zest_mlp_fwd(bf16): plan has %d stream units, kernel expects %d", p.n_tiles,
+                       stream_units(NT_PTS, MOD ? NT_FEAT : 0));
+        return (int)hipErrorInvalidValue;
+    }
     const zest_mlp_desc &d = p.desc;
     const int F = d.use_feat ? d.in_ch_feat : 0;
     const int C_in = d.in_ch_pts + F + d.in_ch_views;
     const int C_out = d.head == ZEST_HEAD_NONE ? 4 : (d.head == ZEST_HEAD_BLEND ? 5 : 12);
     const int blocks = zest_div_up(M, 4 * 32 * NB);
     hipLaunchKernelGGL((mlp_bf16_kernel<NB, NT_PTS, MOD, NT_FEAT>), dim3(blocks), dim3(256), 0, stream,
-                       maps, bias, (const uint4 *)tiles, x, M, d.in_ch_pts, F, C_in, C_out, d.head,
+                       maps, (const uint4 *)tiles, x, M, d.in_ch_pts, F, C_in, C_out, d.head,
                        d.net_type == 2 ? 1 : 0, out);
     ZEST_RETURN_LAUNCH("zest_mlp_fwd(bf16)");
 }
 
-int mlp_bf16_launch(const MlpPlan &p, const float *bias, const void *tiles, const float *x, int M,
-                    float *out, hipStream_t stream) {
+int mlp_bf16_launch(const MlpPlan &p, const void *tiles, const float *x, int M, float *out,
+                    hipStream_t stream) {
     SlotMaps maps;
     for (auto &r : maps.pts) r[0] = r[1] = -1;
     for (auto &r : maps.feat) r[0] = r[1] = -1;
@@ -106,12 +111,12 @@ int mlp_bf16_launch(const MlpPlan &p, const float *bias, const void *tiles, cons
     const bool mod = p.desc.use_feat != 0;
     const int key = p.nt_pts * 10 + (mod ? p.nt_feat : 0);
     switch (key) {
-        case 40: return launch_one<1, 4, false, 0>(p, maps, bias, tiles, x, M, out, stream);
-        case 42: return launch_one<1, 4, true, 2>(p, maps, bias, tiles, x, M, out, stream);
-        case 43: return launch_one<1, 4, true, 3>(p, maps, bias, tiles, x, M, out, stream);
-        case 60: return launch_one<1, 6, false, 0>(p, maps, bias, tiles, x, M, out, stream);
-        case 62: return launch_one<1, 6, true, 2>(p, maps, bias, tiles, x, M, out, stream);
-        case 63: return launch_one<1, 6, true, 3>(p, maps, bias, tiles, x, M, out, stream);
+        case 40: return launch_one<1, 4, false, 0>(p, maps, tiles, x, M, out, stream);
+        case 42: return launch_one<1, 4, true, 2>(p, maps, tiles, x, M, out, stream);
+        case 43: return launch_one<1, 4, true, 3>(p, maps, tiles, x, M, out, stream);
+        case 60: return launch_one<1, 6, false, 0>(p, maps, tiles, x, M, out, stream);
+        case 62: return launch_one<1, 6, true, 2>(p, maps, tiles, x, M, out, stream);
+        case 63: return launch_one<1, 6, true, 3>(p, maps, tiles, x, M, out, stream);
     }
     zest_set_error("zest_mlp_fwd(bf16): no kernel for %d point tiles / %d feature tiles "
                    "(supported: 3..8 source views)", p.nt_pts, mod ? p.nt_feat : 0);

@@ -11,9 +11,10 @@
 // weights).  Row-blocks are the outer loop, so only one accumulator tile (plus one modulation
 // tile) per column block is live next to the 64-register input and output operands.
 //
-// Per 32-sample column block, MOD on, xyz input: 1 376 MFMAs of 32 cycles; the arithmetic
-// intensity against the weight stream is set by how many samples share a tile read
-// (NB x waves per workgroup), see DESIGN.md.
+// The weight stream (units of 1 KiB in consumption order, mlp_plan.h) comes from a `Tiles`
+// source: GlobalTiles reads units straight from global memory (standalone MLP kernel);
+// RingTiles (fused renderer) reads them from an LDS ring that the workgroup's waves keep
+// filled with LDS-DMA (`global_load_lds`), several chunks ahead of the MFMAs.
 #pragma once
 #include <hip/hip_bf16.h>
 #include "mlp_plan.h"
@@ -21,32 +22,139 @@
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) float v4f;
+typedef __attribute__((ext_vector_type(4))) unsigned v4u;
+typedef const __attribute__((address_space(1))) v4u *gptr_u4;        // global memory, 16-byte units
 
 namespace zest {
 
-// Source of weight tiles: v1 reads them straight from global memory (L1/L2 resident).
-struct GlobalTiles {
-    const uint4 *base;     // wave-uniform: first tile of the stream
-    int lane;
-    __device__ __forceinline__ bf16x8 load(int tile) const {
-        const uint4 v = base[(size_t)tile * 64 + lane];
-        return *reinterpret_cast<const bf16x8 *>(&v);
-    }
-};
-
-__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
-    __hip_bfloat162 v = __float22bfloat162_rn(make_float2(lo, hi));
-    return *reinterpret_cast<unsigned *>(&v);
+// units in the stream of one net (mirror of build_plan for ORDER_ACC, checked on the host)
+constexpr int stream_units_raw(int nt_pts, int nt_feat) {
+    const int mod = nt_feat;                       // modulation tiles per row block (0 = off)
+    return 8 * (1 + mod + nt_pts) + 6 * 8 * (1 + mod + 16) + 8 * (1 + mod + nt_pts + 16)   // trunk
+           + (1 + 16) + 8 * (1 + 16) + 4 * (1 + 16 + 2) + (1 + 8);                         // heads
+}
+constexpr int stream_units(int nt_pts, int nt_feat) {
+    return (stream_units_raw(nt_pts, nt_feat) + kStreamAlign - 1) / kStreamAlign * kStreamAlign;
 }
 
-__device__ __forceinline__ f32x16 load_bias_block(const float *__restrict__ bias, int block, int half) {
-    const float4 *b = reinterpret_cast<const float4 *>(bias + (size_t)block * 32 + half * 16);
-    const float4 b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+__device__ __forceinline__ f32x16 f32x16_from(const v4f b0, const v4f b1, const v4f b2, const v4f b3) {
     f32x16 r;
     r[0] = b0.x, r[1] = b0.y, r[2] = b0.z, r[3] = b0.w, r[4] = b1.x, r[5] = b1.y, r[6] = b1.z, r[7] = b1.w;
     r[8] = b2.x, r[9] = b2.y, r[10] = b2.z, r[11] = b2.w, r[12] = b3.x, r[13] = b3.y, r[14] = b3.z, r[15] = b3.w;
     return r;
 }
+
+// ---- weight source 1: global memory --------------------------------------------------------
+struct GlobalTiles {
+    gptr_u4 base;          // wave-uniform: first unit of the stream
+    int lane, half;
+    __device__ __forceinline__ bf16x8 load(int unit) const {
+        const v4u v = base[(size_t)unit * 64 + lane];
+        return *reinterpret_cast<const bf16x8 *>(&v);
+    }
+    // bias block `which` (0 = op bias, 1 = modulation bias) of header unit `unit`
+    __device__ __forceinline__ f32x16 load_bias(int unit, int which) const {
+        const __attribute__((address_space(1))) v4f *b =
+            (const __attribute__((address_space(1))) v4f *)(base + (size_t)unit * 64) + which * 8 + half * 4;
+        return f32x16_from(b[0], b[1], b[2], b[3]);
+    }
+    __device__ __forceinline__ void finish(int, int) const {}
+};
+
+// ---- weight source 2: LDS ring fed by LDS-DMA -----------------------------------------------
+// The ring holds kRingUnits KiB = kSlots chunks of kChunk units.  All NW waves of the
+// workgroup walk the stream in step.  On entering chunk c every wave waits until its own DMA
+// pieces of chunk c have landed (counted vmcnt: the younger kAhead-1 chunks stay in flight),
+// meets the others at a barrier - after which chunk c is complete and chunk c-1 is no longer
+// read by anyone - and issues its share of chunk c+kAhead into the slot that frees.  The
+// stream length is a multiple of the ring size, so unit u always sits at ring offset
+// u % kRingUnits and passes follow each other without draining the ring.
+constexpr int kChunk = 16, kSlots = 8, kRingUnits = kChunk * kSlots, kAhead = 4;
+static_assert(kRingUnits == kStreamAlign, "stream padding must equal the ring size");
+static_assert(kSlots >= kAhead + 1, "a slot is refilled while the previous chunk may still be read");
+
+template <int NW, int UNITS_A, int UNITS_B>
+struct RingTiles {
+    static constexpr int kPieces = kChunk / NW;             // DMA pieces per wave per chunk
+    static constexpr int kChunksA = UNITS_A / kChunk, kChunks = (UNITS_A + UNITS_B) / kChunk;
+    static_assert(kChunk % NW == 0 && UNITS_A % kRingUnits == 0 && UNITS_B % kRingUnits == 0, "");
+    char *ring;            // LDS, kRingUnits KiB, 16-byte aligned
+    gptr_u4 src_a, src_b;  // the two nets' streams (src_b unused when UNITS_B == 0)
+    int lane, half, wave;  // wave: provably uniform (readfirstlane)
+    unsigned voff;         // (wave * kPieces * 64 + lane) * 16: this lane's byte offset in a chunk
+
+    // LDS-DMA of this wave's pieces of a chunk.  Issued through inline asm so that only the
+    // counted waits in enter_chunk govern it: hipcc would otherwise drain vmcnt(0) in front of
+    // every ds_read it cannot prove disjoint from the DMA destination
+    // (cdna_hip_programming.md 5.7; M0 = LDS destination, restored afterwards).  Addressing
+    // is scalar base + 32-bit lane offset: the per-chunk part stays in SGPRs, so there are no
+    // per-chunk address VGPRs for the compiler to hoist out of the pass loop and spill.
+    __device__ __forceinline__ void issue(int chunk) const {      // chunk: compile-time after unrolling
+        const int c = chunk % kChunks;
+        const __attribute__((address_space(1))) char *src =
+            c < kChunksA ? (const __attribute__((address_space(1))) char *)src_a + (size_t)c * kChunk * 1024
+                         : (const __attribute__((address_space(1))) char *)src_b + (size_t)(c - kChunksA) * kChunk * 1024;
+        const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)ring;
+#pragma unroll
+        for (int i = 0; i < kPieces; i++) {
+            const unsigned dst = lds_base + ((c % kSlots) * kChunk + wave * kPieces + i) * 1024;
+            const __attribute__((address_space(1))) char *sb = src + i * 1024;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(voff), "s"(sb), "s"(dst)
+                         : "memory");
+        }
+    }
+    __device__ __forceinline__ void prologue() const {
+#pragma unroll
+        for (int c = 0; c < kAhead; c++) issue(c);
+    }
+    __device__ __forceinline__ void enter_chunk(int chunk) const {
+        // all but the youngest (kAhead-1)*kPieces of this wave's DMA pieces have landed
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"((kAhead - 1) * kPieces) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue(chunk + kAhead);
+    }
+    __device__ __forceinline__ void touch(int unit) const {
+        if (unit % kChunk == 0) enter_chunk(unit / kChunk);
+    }
+    __device__ __forceinline__ bf16x8 load(int unit) const {
+        touch(unit);
+        const v4u v = *reinterpret_cast<const v4u *>(ring + (unit % kRingUnits) * 1024 + lane * 16);
+        return *reinterpret_cast<const bf16x8 *>(&v);
+    }
+    __device__ __forceinline__ f32x16 load_bias(int unit, int which) const {
+        touch(unit);
+        const v4f *b = reinterpret_cast<const v4f *>(ring + (unit % kRingUnits) * 1024 + which * 128 + half * 64);
+        return f32x16_from(b[0], b[1], b[2], b[3]);
+    }
+    // walk the padding [unit, end) of a net's stream so every chunk is entered exactly once
+    __device__ __forceinline__ void finish(int unit, int end) const {
+#pragma unroll
+        for (int u = (unit + kChunk - 1) / kChunk * kChunk; u < end; u += kChunk) enter_chunk(u / kChunk);
+    }
+    __device__ __forceinline__ void drain() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+};
+
+// two fp32 -> packed bf16 pair (round to nearest even): one v_cvt_pk_bf16_f32.  Written as a
+// vector conversion the compiler understands - an inline-asm form would read MFMA results
+// without the wait states hipcc inserts for its own instructions (cdna guide 5.7 item 2) -
+// and not as __float22bfloat162_rn, which costs 2 cvt + shift + or on MFMA tile elements.
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    const f32x2_t f = {lo, hi};
+    const bf16x2_t r = __builtin_convertvector(f, bf16x2_t);
+    return *reinterpret_cast<const unsigned *>(&r);
+}
+
+// relu as one v_med3_f32: max(v, 0) for every finite activation (fmaxf costs a second,
+// canonicalising v_max in front; med3 against a finite bound is not folded back into it)
+__device__ __forceinline__ float relu1(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 3.0e38f); }
 
 // 16 activated fp32 values of a tile -> the two bf16 operand tiles they form
 __device__ __forceinline__ void acc_to_operand(const f32x16 &v, bf16x8 &t0, bf16x8 &t1) {
@@ -68,24 +176,24 @@ struct OpArr {              // N operand tiles; N = 0 allowed
 //   MODE: 0 = produce operand tiles into `out` (2 per row block), 1 = keep the accumulator of
 //         row block 0 in `keep` (head / rgb tiles)
 template <int NB, int NJB, int NTA, int NTB, bool MOD, int NTF, bool RELU, int MODE, class Tiles>
-__device__ __forceinline__ void engine_layer(const Tiles &tiles, int &tile, const float *__restrict__ bias,
-                                             int bias_block, int half, bool v2,
+__device__ __forceinline__ void engine_layer(const Tiles &tiles, int &unit, bool v2,
                                              const OpArr<NTA> (&opa)[NB], const OpArr<NTB> (&opb)[NB],
                                              const OpArr<NTF> (&opf)[NB], OpArr<16> (&out)[NB],
                                              f32x16 (&keep)[NB]) {
 #pragma unroll
     for (int jb = 0; jb < NJB; jb++) {
         f32x16 acc[NB], macc[NB];
-        const f32x16 b0 = load_bias_block(bias, bias_block + jb, half);
+        const int hdr = unit++;
+        const f32x16 b0 = tiles.load_bias(hdr, 0);
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) acc[nb] = b0;
         if (MOD) {
-            const f32x16 m0 = load_bias_block(bias, jb, half);
+            const f32x16 m0 = tiles.load_bias(hdr, 1);
 #pragma unroll
             for (int nb = 0; nb < NB; nb++) macc[nb] = m0;
 #pragma unroll
             for (int k = 0; k < NTF; k++) {
-                const bf16x8 a = tiles.load(tile++);
+                const bf16x8 a = tiles.load(unit++);
 #pragma unroll
                 for (int nb = 0; nb < NB; nb++)
                     macc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, opf[nb].t[k], macc[nb], 0, 0, 0);
@@ -93,14 +201,14 @@ __device__ __forceinline__ void engine_layer(const Tiles &tiles, int &tile, cons
         }
 #pragma unroll
         for (int k = 0; k < NTA; k++) {
-            const bf16x8 a = tiles.load(tile++);
+            const bf16x8 a = tiles.load(unit++);
 #pragma unroll
             for (int nb = 0; nb < NB; nb++)
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, opa[nb].t[k], acc[nb], 0, 0, 0);
         }
 #pragma unroll
         for (int k = 0; k < NTB; k++) {
-            const bf16x8 a = tiles.load(tile++);
+            const bf16x8 a = tiles.load(unit++);
 #pragma unroll
             for (int nb = 0; nb < NB; nb++)
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, opb[nb].t[k], acc[nb], 0, 0, 0);
@@ -114,64 +222,57 @@ __device__ __forceinline__ void engine_layer(const Tiles &tiles, int &tile, cons
             }
             if (RELU) {
 #pragma unroll
-                for (int i = 0; i < 16; i++) v[i] = fmaxf(v[i], 0.0f);
+                for (int i = 0; i < 16; i++) v[i] = relu1(v[i]);
             }
             if (MODE == 0)
                 acc_to_operand(v, out[nb].t[2 * jb], out[nb].t[2 * jb + 1]);
             else if (jb == 0)
                 keep[nb] = v;
         }
+#ifdef ZEST_SCHED_FENCE
+        __builtin_amdgcn_sched_barrier(0);
+#endif
     }
 }
 
-// The whole network for NB column blocks.  pts/feat/views: encoder operands in plan slot
-// order.  Results: head tile (row 0 alpha, rows 1.. extra heads) and rgb tile (rows 0-2),
-// raw (no output activation).
+// The whole network for NB column blocks, reading the stream from unit `unit` on (advanced to
+// the end of the net's padded stream).  pts/feat/views: encoder operands in plan slot order.
+// Results: head tile (row 0 alpha, rows 1.. extra heads) and rgb tile (rows 0-2), raw.
 template <int NB, int NT_PTS, bool MOD, int NT_FEAT, class Tiles>
-__device__ __forceinline__ void engine_forward(const Tiles &tiles, const float *__restrict__ bias,
-                                               int half, bool v2, const OpArr<NT_PTS> (&pts)[NB],
+__device__ __forceinline__ void engine_forward(const Tiles &tiles, int &unit, bool v2,
+                                               const OpArr<NT_PTS> (&pts)[NB],
                                                const OpArr<NT_FEAT> (&feat)[NB],
                                                const OpArr<2> (&views)[NB], f32x16 (&head)[NB],
                                                f32x16 (&rgb)[NB]) {
     OpArr<16> hA[NB], hB[NB];
     OpArr<0> none[NB];
     f32x16 unused[NB];
-    int tile = 0;
-    int bb = MOD ? 8 : 0;
-    engine_layer<NB, 8, NT_PTS, 0, MOD, NT_FEAT, true, 0>(tiles, tile, bias, bb, half, v2, pts, none, feat, hA, unused);
-    bb += 8;
-    engine_layer<NB, 8, 16, 0, MOD, NT_FEAT, true, 0>(tiles, tile, bias, bb, half, v2, hA, none, feat, hB, unused);
-    bb += 8;
-    engine_layer<NB, 8, 16, 0, MOD, NT_FEAT, true, 0>(tiles, tile, bias, bb, half, v2, hB, none, feat, hA, unused);
-    bb += 8;
-    engine_layer<NB, 8, 16, 0, MOD, NT_FEAT, true, 0>(tiles, tile, bias, bb, half, v2, hA, none, feat, hB, unused);
-    bb += 8;
-    engine_layer<NB, 8, 16, 0, MOD, NT_FEAT, true, 0>(tiles, tile, bias, bb, half, v2, hB, none, feat, hA, unused);
-    bb += 8;
-    engine_layer<NB, 8, NT_PTS, 16, MOD, NT_FEAT, true, 0>(tiles, tile, bias, bb, half, v2, pts, hA, feat, hB, unused);
-    bb += 8;
-    engine_layer<NB, 8, 16, 0, MOD, NT_FEAT, true, 0>(tiles, tile, bias, bb, half, v2, hB, none, feat, hA, unused);
-    bb += 8;
-    engine_layer<NB, 8, 16, 0, MOD, NT_FEAT, true, 0>(tiles, tile, bias, bb, half, v2, hA, none, feat, hB, unused);
-    bb += 8;
+    const int unit0 = unit;
+    engine_layer<NB, 8, NT_PTS, 0, MOD, NT_FEAT, true, 0>(tiles, unit, v2, pts, none, feat, hA, unused);
+    engine_layer<NB, 8, 16, 0, MOD, NT_FEAT, true, 0>(tiles, unit, v2, hA, none, feat, hB, unused);
+    engine_layer<NB, 8, 16, 0, MOD, NT_FEAT, true, 0>(tiles, unit, v2, hB, none, feat, hA, unused);
+    engine_layer<NB, 8, 16, 0, MOD, NT_FEAT, true, 0>(tiles, unit, v2, hA, none, feat, hB, unused);
+    engine_layer<NB, 8, 16, 0, MOD, NT_FEAT, true, 0>(tiles, unit, v2, hB, none, feat, hA, unused);
+    engine_layer<NB, 8, NT_PTS, 16, MOD, NT_FEAT, true, 0>(tiles, unit, v2, pts, hA, feat, hB, unused);
+    engine_layer<NB, 8, 16, 0, MOD, NT_FEAT, true, 0>(tiles, unit, v2, hB, none, feat, hA, unused);
+    engine_layer<NB, 8, 16, 0, MOD, NT_FEAT, true, 0>(tiles, unit, v2, hA, none, feat, hB, unused);
     // trunk output in hB
-    engine_layer<NB, 1, 16, 0, false, NT_FEAT, false, 1>(tiles, tile, bias, bb, half, v2, hB, none, feat, hA, head);
-    bb += 1;
-    engine_layer<NB, 8, 16, 0, false, NT_FEAT, false, 0>(tiles, tile, bias, bb, half, v2, hB, none, feat, hA, unused);
-    bb += 8;
-    engine_layer<NB, 4, 16, 2, false, NT_FEAT, true, 0>(tiles, tile, bias, bb, half, v2, hA, views, feat, hB, unused);
-    bb += 4;
+    engine_layer<NB, 1, 16, 0, false, NT_FEAT, false, 1>(tiles, unit, v2, hB, none, feat, hA, head);
+    engine_layer<NB, 8, 16, 0, false, NT_FEAT, false, 0>(tiles, unit, v2, hB, none, feat, hA, unused);
+    engine_layer<NB, 4, 16, 2, false, NT_FEAT, true, 0>(tiles, unit, v2, hA, views, feat, hB, unused);
     // rgb: 128 hidden features = first 8 tiles of hB
     OpArr<8> h128[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; nb++)
 #pragma unroll
         for (int k = 0; k < 8; k++) h128[nb].t[k] = hB[nb].t[k];
-    engine_layer<NB, 1, 8, 0, false, NT_FEAT, false, 1>(tiles, tile, bias, bb, half, v2, h128, none, feat, hA, rgb);
+    engine_layer<NB, 1, 8, 0, false, NT_FEAT, false, 1>(tiles, unit, v2, h128, none, feat, hA, rgb);
+    tiles.finish(unit, unit0 + stream_units(NT_PTS, MOD ? NT_FEAT : 0));
+    unit = unit0 + stream_units(NT_PTS, MOD ? NT_FEAT : 0);
 }
 
 // standalone launcher (mlp.hip -> zest_mlp_fwd)
-int mlp_bf16_launch(const MlpPlan &p, const float *bias, const void *tiles, const float *x, int M,
-                    float *out, hipStream_t stream);
+int mlp_bf16_launch(const MlpPlan &p, const void *tiles, const float *x, int M, float *out,
+                    hipStream_t stream);
 
 }  // namespace zest

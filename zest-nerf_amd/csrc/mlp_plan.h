@@ -17,10 +17,16 @@
 // 4 for f32 = four 32x32x2 MFMAs): lane l, element e holds
 //   W[row0 + (l & 31)][col(feature(tile*SPT + e, l >> 5))]     (0 outside the matrix).
 // The stream is laid out in consumption order: for op, for row-block jb:
-// [modulation tiles over the feature operand] then one run of tiles per operand segment.
-// Biases live in a separate area: one 128-byte block per (op, jb) holding the accumulator
-// initialiser [half][16] = bias[32 jb + (i&3) + 8 (i>>2) + 4 half]; the eight modulation
-// blocks come first.
+// [header] [modulation tiles over the feature operand] then one run of tiles per operand
+// segment.  A bias block is 128 bytes: the accumulator initialiser [half][16] =
+// bias[32 jb + (i&3) + 8 (i>>2) + 4 half].
+//   ORDER_NATURAL (fp32 kernel): no headers; blocks live in a separate bias area in front of
+//     the tiles, the eight modulation blocks first, then one per (op, jb).
+//   ORDER_ACC (bf16 engine): the header is one 1 KiB unit in the stream itself holding the
+//     (op, jb) bias block at byte 0 and the modulation bias block of jb at byte 128, so the
+//     stream is self-contained and can be fed through an LDS ring; it is padded with zero
+//     units to a multiple of kStreamAlign units so a ring of that many units keeps a fixed
+//     phase from one pass to the next.
 #pragma once
 #include <stdint.h>
 #include <vector>
@@ -31,6 +37,7 @@ namespace zest {
 constexpr int kW = 256;            // trunk width (every shipped config: netwidth = 256)
 constexpr int kNumOps = 12;
 constexpr int kMaxSeg = 2;
+constexpr int kStreamAlign = 128;  // units (KiB): ring size the bf16 stream is padded to
 
 // slot-order conventions for operands that are produced from accumulator tiles
 enum SlotOrder {
@@ -51,8 +58,8 @@ struct OpPlan {
     SegPlan seg[kMaxSeg];
     int mod;                 // 1: modulated trunk layer
     int relu;                // 1: relu in the epilogue
-    int tile_base;           // first tile of the op in the stream
-    int tiles_per_jb;        // including modulation tiles
+    int tile_base;           // first unit of the op in the stream
+    int tiles_per_jb;        // including header and modulation tiles
     int bias_block;          // first bias block (128 B units)
 };
 
@@ -62,7 +69,8 @@ struct MlpPlan {
     int spt;                       // slots per tile
     int ns_pts, ns_feat, ns_views; // padded slot counts of the encoder operands
     int nt_pts, nt_feat, nt_views, nt_h, nt_h128;
-    int n_tiles, n_bias_blocks;
+    int headers;                   // 1: ORDER_ACC stream with inline header units
+    int n_tiles, n_bias_blocks;    // n_tiles includes headers and tail padding
     size_t bias_bytes, bytes;      // bias area (padded to 1 KiB) and total
     OpPlan op[kNumOps];
     // feature index (column within the operand's own input range) per slot and half; -1 = pad
@@ -70,6 +78,8 @@ struct MlpPlan {
     // gather tables for the packer: per packed weight element / bias float, source
     // (param_slot << 24 | element offset), 0xFFFFFFFF = zero
     std::vector<uint32_t> tile_src, bias_src;
+    // headers mode: per unit, 64 fp32 sources of the header payload (only header units are set)
+    std::vector<uint32_t> hdr_src;
 };
 
 // Builds the plan; returns false (with *err set) for shapes the kernels do not cover.

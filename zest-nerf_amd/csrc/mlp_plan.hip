@@ -97,6 +97,7 @@ bool build_plan(const zest_mlp_desc &d, int precision, int order, MlpPlan *P, co
     p.nt_h = 128 / spt, p.nt_h128 = 64 / spt;
 
     // ---- op table ----------------------------------------------------------------------
+    p.headers = order == ORDER_ACC ? 1 : 0;
     int tile = 0, bblk = d.use_feat ? 8 : 0;
     for (int o = 0; o < kNumOps; o++) {
         OpPlan &op = p.op[o];
@@ -108,11 +109,12 @@ bool build_plan(const zest_mlp_desc &d, int precision, int order, MlpPlan *P, co
         if (o == 8) op.njb = 1;
         if (o == 10) op.njb = 4, op.relu = 1, op.nseg = 2, op.seg[1] = {SEG_VIEWS, p.nt_views};
         if (o == 11) op.njb = 1, op.seg[0] = {SEG_H, p.nt_h128};
-        op.tiles_per_jb = op.mod ? p.nt_feat : 0;
+        op.tiles_per_jb = (op.mod ? p.nt_feat : 0) + p.headers;
         for (int s = 0; s < op.nseg; s++) op.tiles_per_jb += op.seg[s].ntiles;
         op.tile_base = tile, op.bias_block = bblk;
         tile += op.njb * op.tiles_per_jb, bblk += op.njb;
     }
+    if (p.headers) tile = round_up(tile, kStreamAlign), bblk = 0;
     p.n_tiles = tile, p.n_bias_blocks = bblk;
     p.bias_bytes = (size_t)round_up(bblk * 128, 1024);
     p.bytes = p.bias_bytes + (size_t)tile * 1024;
@@ -123,6 +125,7 @@ bool build_plan(const zest_mlp_desc &d, int precision, int order, MlpPlan *P, co
     const uint32_t ZERO = 0xFFFFFFFFu;
     p.tile_src.assign((size_t)tile * 64 * spt, ZERO);
     p.bias_src.assign(p.bias_bytes / 4, ZERO);
+    p.hdr_src.assign(p.headers ? (size_t)tile * 64 : 0, ZERO);   // 64 floats at the head of a header unit
 
     auto row_src = [&](int o, int row) -> RowSrc {
         if (o < 8) return {ZEST_P_PTS0 + o, row};
@@ -155,22 +158,31 @@ bool build_plan(const zest_mlp_desc &d, int precision, int order, MlpPlan *P, co
                         ((uint32_t)rs.param << 24) | (uint32_t)(rs.row * ld[rs.param] + col0 + feat);
                 }
     };
-    auto emit_bias = [&](int block, int o, int jb, bool is_mod) {
+    auto emit_bias_to = [&](std::vector<uint32_t> &dst, size_t at, int o, int jb, bool is_mod) {
         for (int h = 0; h < 2; h++)
             for (int i = 0; i < 16; i++) {
                 const int row = 32 * jb + (i & 3) + 8 * (i >> 2) + 4 * h;
                 RowSrc rs = is_mod ? RowSrc{ZEST_P_PTS_BIAS, row} : row_src(o, row);
                 if (rs.param < 0) continue;
-                p.bias_src[(size_t)block * 32 + h * 16 + i] = ((uint32_t)rs.param << 24) | rs.row;
+                dst[at + h * 16 + i] = ((uint32_t)rs.param << 24) | rs.row;
             }
     };
-    if (d.use_feat)
+    auto emit_bias = [&](int block, int o, int jb, bool is_mod) {
+        emit_bias_to(p.bias_src, (size_t)block * 32, o, jb, is_mod);
+    };
+    if (d.use_feat && !p.headers)
         for (int jb = 0; jb < 8; jb++) emit_bias(jb, 0, jb, true);
     for (int o = 0; o < kNumOps; o++) {
         const OpPlan &op = p.op[o];
         int t = op.tile_base;
         for (int jb = 0; jb < op.njb; jb++) {
-            emit_bias(op.bias_block + jb, o, jb, false);
+            if (p.headers) {
+                emit_bias_to(p.hdr_src, (size_t)t * 64, o, jb, false);
+                if (op.mod) emit_bias_to(p.hdr_src, (size_t)t * 64 + 32, o, jb, true);
+                t++;
+            } else {
+                emit_bias(op.bias_block + jb, o, jb, false);
+            }
             if (op.mod) emit_tiles(t, o, jb, SegPlan{SEG_FEAT, p.nt_feat}, 0, true);
             int col0 = 0;
             for (int s = 0; s < op.nseg; s++) {

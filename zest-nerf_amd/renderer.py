@@ -143,6 +143,34 @@ def _net(network_fn, what):
     return network_fn
 
 
+def _render_maps_fused(rays_ndc, ndc, pts, z, dirs, net_s, network_fn_dy, scene_flow, vol_s, vol_d,
+                       imgs, nb_imgs, cam, nb_cam, embedding_xyzt, embedding_dir, ref_frame_idx,
+                       white_bkgd, raw_noise_std):
+    """Per-ray maps only, one kernel launch (zest_render_fused_fwd).  Returns the per-ray keys
+    of the reference dict (plus 'acc_map'); per-sample keys are not produced."""
+    if raw_noise_std > 0:
+        raise NotImplementedError("zest fused renderer: density noise is a training-time option")
+    vs = _Views(vol_s, imgs, cam)
+    views_s = zest_hip.make_view_set(vs.vol_cl, vs.imgs_cl, vs.w2cs, vs.intr)
+    desc_d = packed_d = views_d = None
+    if scene_flow:
+        net_d = _net(network_fn_dy, "network_fn_dy")
+        _check_embedders(embedding_xyzt, embedding_dir, 4)
+        vd = _Views(vol_d, nb_imgs, nb_cam)
+        desc_d, packed_d = net_d.desc(), net_d.packed(zest_hip.PREC_BF16)
+        views_d = zest_hip.make_view_set(vd.vol_cl, vd.imgs_cl, vd.w2cs, vd.intr)
+    out = zest_hip.render_fused(ndc, pts, z, dirs, net_s.desc(), net_s.packed(zest_hip.PREC_BF16),
+                                views_s, desc_d, packed_d, views_d,
+                                ref_frame_idx if scene_flow else 0.0, white_bkgd)
+    ret = {'rgb_map': out[None, :, 0:3], 'depth_map': out[None, :, 3], 'acc_map': out[None, :, 4],
+           'zest_packed_maps': out}
+    if scene_flow:
+        ret.update({'rgb_map_ref': out[None, :, 5:8], 'depth_map_ref': out[None, :, 8],
+                    'rgb_map_ref_dy': out[None, :, 9:12], 'depth_map_ref_dy': out[None, :, 12],
+                    'weights_map_dd': out[None, :, 13]})
+    return ret
+
+
 # ------------------------------------------------------------------------------- rendering
 def rendering(args, rays_pts, rays_ndc, depth_candidates, rays_dir,
               volume_feature_static=None, volume_feature_dynamic=None,
@@ -175,6 +203,12 @@ def rendering(args, rays_pts, rays_ndc, depth_candidates, rays_dir,
     if torch.is_grad_enabled() and any(p.requires_grad for p in net_s.parameters()):
         raise NotImplementedError("zest renderer: backward kernels are not built yet "
                                   "(SURVEY.md 8(f) next-2); call under torch.no_grad()")
+
+    if prec == zest_hip.PREC_BF16 and getattr(args, "zest_maps_only", False) and (val or not scene_flow):
+        return _render_maps_fused(rays_ndc, ndc, pts, z, dirs, net_s, network_fn_dy, scene_flow,
+                                  volume_feature_static, volume_feature_dynamic, imgs,
+                                  neighbour_frames, im_cam_mat, nb_cam_mat, embedding_xyzt,
+                                  embedding_dir, ref_frame_idx, white_bkgd, raw_noise_std)
 
     def mlp(net, x):
         return zest_hip.mlp_fwd(net.desc(), prec, net.packed(prec), x)

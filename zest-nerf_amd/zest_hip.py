@@ -60,7 +60,8 @@ _SIGS = {
     "zest_mlp_fwd": (_i, [C.POINTER(MlpDesc), _i, _vp, _vp, _i, _vp, _vp]),
     "zest_render_fused_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, C.POINTER(MlpDesc), _vp,
                                    C.POINTER(ViewSet), C.POINTER(MlpDesc), _vp, C.POINTER(ViewSet),
-                                   _f, _i, _i, _vp, _vp]),
+                                   _f, _i, _i, _vp, _vp, _vp]),
+    "zest_render_fused_workspace": (_sz, [_i, _i]),
 }
 
 _lib = None
@@ -290,3 +291,44 @@ def param_table(state, desc, prefix="nerf."):
         put(13, "sf_linear")
         put(14, "prob_linear")
     return tab
+
+
+# ----------------------------------------------------------------------------- fused renderer
+def make_view_set(vol_cl=None, imgs_cl=None, w2cs=None, intrinsics=None):
+    """Pack the feature sources of one net into the C struct; keeps the tensors alive."""
+    vs = ViewSet()
+    keep = []
+    if vol_cl is not None:
+        vs.vol_cl, (vs.D, vs.Hv, vs.Wv) = _ptr(vol_cl), vol_cl.shape[:3]
+        vs.imgs_cl, (vs.V, vs.H, vs.W) = _ptr(imgs_cl), imgs_cl.shape[:3]
+        keep += [vol_cl, imgs_cl]
+    if w2cs is not None:
+        w2cs = _dev(w2cs, "w2cs")
+        vs.w2cs = _ptr(w2cs)
+        keep.append(w2cs)
+    if intrinsics is not None:
+        intrinsics = _dev(intrinsics, "intrinsics")
+        vs.intrinsics = _ptr(intrinsics)
+        keep.append(intrinsics)
+    vs._keep = keep
+    return vs
+
+
+def render_fused(ndc, pts, z, rays_dir, desc_s, packed_s, views_s, desc_d=None, packed_d=None,
+                 views_d=None, frame_idx=0.0, white_bkgd=False, out=None, workspace=None):
+    """One launch for the inference path.  ndc, pts [R,S,3]; z [R,S]; rays_dir [R,3].
+    Returns out [R,16] (column layout: include/zest_render.h)."""
+    ndc, pts, z, rays_dir = _dev(ndc, "ndc"), _dev(pts, "pts"), _dev(z, "z"), _dev(rays_dir, "rays_dir")
+    R, S = z.shape
+    if out is None:
+        out = torch.empty(R, 16, device=z.device, dtype=torch.float32)
+    need = int(lib().zest_render_fused_workspace(R, S))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, device=z.device, dtype=torch.uint8)
+    _check(lib().zest_render_fused_fwd(
+        _ptr(ndc), _ptr(pts), _ptr(z), _ptr(rays_dir), R, S, C.byref(desc_s), _ptr(packed_s),
+        C.byref(views_s) if views_s is not None else None,
+        C.byref(desc_d) if desc_d is not None else None, _ptr(packed_d),
+        C.byref(views_d) if views_d is not None else None, float(frame_idx), PREC_BF16,
+        int(bool(white_bkgd)), _ptr(workspace), _ptr(out), _stream(z)), "zest_render_fused_fwd")
+    return out

@@ -46,7 +46,7 @@ bool fill_net(const zest_mlp_desc *d, const void *packed, const zest_view_set *v
     if (!d || !packed) return *err = "descriptor and packed weights are required", false;
     if (d->in_ch_pts != pts_ch) return *err = "unexpected in_ch_pts for this slot", false;
     zest::MlpPlan plan;
-    if (!zest::build_plan(*d, ZEST_PREC_BF16, zest::ORDER_ACC, &plan, err)) return false;
+    if (!zest::build_plan(*d, ZEST_PREC_BF16, zest::ORDER_ACC, &plan, err, false)) return false;
     n->bias = (const float *)packed;
     n->tiles = (const uint4 *)((const char *)packed + plan.bias_bytes);
     n->head = d->head, n->v2 = d->net_type == 2;

@@ -83,6 +83,8 @@ struct MlpPlan {
 };
 
 // Builds the plan; returns false (with *err set) for shapes the kernels do not cover.
-bool build_plan(const zest_mlp_desc &d, int precision, int order, MlpPlan *out, const char **err);
+// with_tables = false skips the packer's gather tables (cheap: launch-time shape queries).
+bool build_plan(const zest_mlp_desc &d, int precision, int order, MlpPlan *out, const char **err,
+                bool with_tables = true);
 
 }  // namespace zest

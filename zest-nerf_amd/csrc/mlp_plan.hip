@@ -58,7 +58,8 @@ struct RowSrc { int param, row; };       // param < 0: zero row
 
 }  // namespace
 
-bool build_plan(const zest_mlp_desc &d, int precision, int order, MlpPlan *P, const char **err) {
+bool build_plan(const zest_mlp_desc &d, int precision, int order, MlpPlan *P, const char **err,
+                bool with_tables) {
     static const char *e_prec = "precision must be ZEST_PREC_F32 or ZEST_PREC_BF16";
     static const char *e_pts = "in_ch_pts must be 63 (xyz, L=10) or 84 (xyzt, L=10)";
     static const char *e_views = "in_ch_views must be 27 (L=4)";
@@ -119,6 +120,7 @@ bool build_plan(const zest_mlp_desc &d, int precision, int order, MlpPlan *P, co
     p.bias_bytes = (size_t)round_up(bblk * 128, 1024);
     p.bytes = p.bias_bytes + (size_t)tile * 1024;
 
+    if (!with_tables) return true;
     // ---- gather tables -------------------------------------------------------------------
     const int ld[ZEST_P_COUNT] = {d.in_ch_pts, kW, kW, kW, kW, kW + d.in_ch_pts, kW, kW,
                                   d.in_ch_feat, kW + d.in_ch_views, kW, kW, kW / 2, kW, kW};

@@ -103,6 +103,17 @@ def flops_per_ray_batch(d):
     return f * d.R * d.S, f
 
 
+def pmc_traffic(workload):
+    """HBM bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes,
+    gfx950 correction: FETCH_SIZE counts half of a wide coalesced read) and archived by
+    tools/pmc_traffic.py; None when no measurement exists for the workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(d, budget_s=15.0):
     """Oracle (reference op sequence, PyTorch-CPU fp32, all host cores) on the first rays of the
     same workload; bounded to ~budget_s seconds."""
@@ -168,12 +179,12 @@ def main():
     import zest_hip
     zest_hip.lib()
     d = build_workload(a.workload, 1234 + rank, dev, a.rays)
-    gathered = torch.empty(world * d.R, 16, device=dev) if world > 1 else None
+    import zest_parallel
 
     def step():
         ret = render_step(d)
-        if world > 1:       # all-gather of the rendered pixels over RCCL/xGMI
-            dist.all_gather_into_tensor(gathered, ret["zest_packed_maps"])
+        if world > 1:       # ONE all-gather of the packed per-ray maps over RCCL/xGMI
+            return zest_parallel.gather_maps(ret["zest_packed_maps"], world * d.R)
         return ret
 
     def fence():
@@ -216,8 +227,12 @@ def main():
                        "note": d.cfg["note"], "path": "renderer.rendering -> zest_render_fused_fwd",
                        "collective": "all_gather(rendered pixels)" if world > 1 else "none"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
-                         "kernel": "fused_render_kernel", "kernel_ms": k_ms, "flop_per_sample": fps},
+                         "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(a.workload),
+                         "kernel": "fused_blocks_kernel (+ fused_combine_kernel, ~3% of the bracket)",
+                         "kernel_ms": k_ms, "flop_per_sample": fps,
+                         "note": "achieved = algorithmic MLP FLOPs of one launch / HIP-event time of the "
+                                 "launch pair on its stream; traffic = HBM bytes per launch from the "
+                                 "rocprofv3 PMC passes archived in profiles/ (null if none for this workload)"},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(d, a.cpu_budget)

@@ -1,0 +1,85 @@
+"""CPU, world_size 2 over gloo: ray sharding + all-gather of rendered maps reproduces the
+single-process result (the N > 1 path of bench.py / zest_parallel.py).  The per-shard render
+function here is the oracle; on GPUs it is renderer.rendering."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, R, out_q):
+    for p in (os.path.join(ROOT, "zest-nerf_amd"), os.path.join(ROOT, "tests"), ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    import golden_cases as gc
+    import zest_parallel as zp
+    from oracle import zest_oracle as zo
+    inp = gc.composite_inputs(5, R=R, S=24, dead_ray=False)
+    rays = {k: torch.from_numpy(v) for k, v in inp.items()}
+
+    def render(loc):
+        z, d = loc["z"], loc["rays_dir"]
+        dists = zo.sample_dists(z, torch.linalg.vector_norm(d, dim=-1, keepdim=True))
+        rgb, _, acc, _, depth, _ = zo.composite(loc["raw"], z, dists)
+        return torch.cat([rgb, depth[:, None], acc[:, None]], -1)
+
+    full = zp.render_sharded(render, rays, R)
+    lo, hi, per = zp.shard_bounds(R, world, rank)
+    out_q.put((rank, full.numpy(), (lo, hi, per)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("R", [32, 37, 3])
+def test_shard_gather_matches_single_process(R):
+    import golden_cases as gc
+    from oracle import zest_oracle as zo
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, R, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    inp = gc.composite_inputs(5, R=R, S=24, dead_ray=False)
+    z, d, raw = (torch.from_numpy(inp[k]) for k in ("z", "rays_dir", "raw"))
+    dists = zo.sample_dists(z, torch.linalg.vector_norm(d, dim=-1, keepdim=True))
+    rgb, _, acc, _, depth, _ = zo.composite(raw, z, dists)
+    want = torch.cat([rgb, depth[:, None], acc[:, None]], -1).numpy()
+    bounds = sorted(b for _, _, b in got)
+    assert bounds[0][0] == 0 and bounds[-1][1] == R and bounds[0][1] == bounds[1][0]
+    for rank, full, _ in got:
+        assert full.shape == want.shape
+        assert np.array_equal(full, want), "rank %d" % rank      # same ops per ray: bit-exact
+
+
+def test_shard_bounds_cover_all_rays():
+    import zest_parallel as zp
+    for R in (0, 1, 7, 8, 1024, 1025):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for rank in range(world):
+                lo, hi, per = zp.shard_bounds(R, world, rank)
+                assert 0 <= lo <= hi <= R and hi - lo <= per
+                seen += list(range(lo, hi))
+            assert seen == list(range(R))

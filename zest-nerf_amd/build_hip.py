@@ -45,9 +45,15 @@ def _compile(src, extra):
     return obj
 
 
-def build(force=False, extra_flags=()):
+def build(force=False, extra_flags=(), tag=None, only=None):
+    """tag: build an experiment variant libzest_hip_<tag>.so with extra -D flags (objects kept
+    apart); only: restrict to these sources (others are taken from the default build)."""
+    global OBJ, LIB
+    if tag:
+        OBJ = os.path.join(CSRC, "build_" + tag)
+        LIB = os.path.join(HERE, "libzest_hip_%s.so" % tag)
     os.makedirs(OBJ, exist_ok=True)
-    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s)) and (not only or s in only)]
     if force:
         for s in srcs:
             o = os.path.join(OBJ, s.replace(".hip", ".o"))
@@ -64,4 +70,7 @@ def build(force=False, extra_flags=()):
 
 
 if __name__ == "__main__":
-    print(build(force="-f" in sys.argv))
+    # python build_hip.py [-f] [--tag NAME -DFOO=1 ...]
+    argv = sys.argv[1:]
+    tag = argv[argv.index("--tag") + 1] if "--tag" in argv else None
+    print(build(force="-f" in argv, extra_flags=[a for a in argv if a.startswith("-D")], tag=tag))

@@ -47,29 +47,47 @@ __device__ __forceinline__ bf16x8 pack_tile(const float (&v)[8]) {
     return *reinterpret_cast<bf16x8 *>(&a);
 }
 
+// swap the two 32-lane halves of a register (v_permlane32_swap, no LDS)
+__device__ __forceinline__ float swap_halves(float v, int half) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(half ? r[0] : r[1]);
+}
+
 // Positional-encoding operand for C coordinates and L bands in plan slot order
 // (mlp_plan.hip pe_map_acc): slot q < L*C holds sin (half 0) / cos (half 1) of
 // 2^(q/C) * x[q%C]; then the raw coordinates two per slot; zero padding after that.
+// Both lane halves own the same sample, so they split the arguments: for the pair (q, q+1)
+// half 0 evaluates sincos of argument q, half 1 of q+1, and one half-swap hands the partner
+// the value it needs (cos q to half 1, sin q+1 to half 0): L*C/2 sincos per lane, not L*C.
 template <int C, int L, int NT>
 __device__ __forceinline__ void encode_pe_operand(const float (&x)[4], int half, OpArr<NT> &op) {
+    static_assert((L * C) % 2 == 0 && L * C + (C + 1) / 2 <= NT * 8, "slot layout");
+    float val[NT * 8];
+#pragma unroll
+    for (int q = L * C; q < NT * 8; q++) {
+        const int p = q - L * C;
+        val[q] = 0.0f;
+        if (p < (C + 1) / 2) {
+            const float lo = x[2 * p], hi = (2 * p + 1 < C) ? x[2 * p + 1] : 0.0f;
+            val[q] = half ? hi : lo;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < L * C; q += 2) {
+        const float a0 = x[q % C] * (float)(1 << (q / C));
+        const float a1 = x[(q + 1) % C] * (float)(1 << ((q + 1) / C));
+        float s, c;
+        zest_sincos(half ? a1 : a0, &s, &c);
+        const float other = swap_halves(half ? s : c, half);   // half 0 gets sin(a1), half 1 cos(a0)
+        val[q] = half ? other : s;
+        val[q + 1] = half ? c : other;
+    }
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const int q = 8 * t + e;
-            if (q < L * C) {
-                float s, c;
-                zest_sincos(x[q % C] * (float)(1 << (q / C)), &s, &c);
-                v[e] = half ? c : s;
-            } else if (q < L * C + (C + 1) / 2) {
-                const int p = q - L * C;
-                const float lo = x[2 * p], hi = (2 * p + 1 < C) ? x[2 * p + 1] : 0.0f;
-                v[e] = half ? hi : lo;
-            } else {
-                v[e] = 0.0f;
-            }
-        }
+        for (int e = 0; e < 8; e++) v[e] = val[8 * t + e];
         op.t[t] = pack_tile(v);
     }
 }
@@ -173,7 +191,10 @@ struct BlockSamples {              // what a lane keeps about its sample across 
 // block is composited on its own with entry transmittance 1 and leaves a record (exit
 // transmittance + weighted sums); combine_kernel chains the records of a ray.
 template <int NT_FEAT_S, bool DYN, int NT_FEAT_D>
-__global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves / 4) void fused_blocks_kernel(FusedArgs a) {
+#ifndef ZEST_FUSED_WG_PER_CU
+#define ZEST_FUSED_WG_PER_CU 1
+#endif
+__global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_CU / 4) void fused_blocks_kernel(FusedArgs a) {
     constexpr bool MOD_S = NT_FEAT_S > 0, MOD_D = NT_FEAT_D > 0;
     constexpr int NB = kFusedNB;
     constexpr int UNITS_S = stream_units(4, NT_FEAT_S), UNITS_D = DYN ? stream_units(6, NT_FEAT_D) : 0;
@@ -215,8 +236,20 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves / 4) void fused_block
     for (int pass = blockIdx.x; pass < n_pass; pass += gridDim.x) {
         int unit = 0;
         f32x16 head_s[NB], rgb_s[NB], head_d[NB], rgb_d[NB];
+        // direction operand of net `n`, built when the engine reaches the view layer
+        auto views_of = [&](const FusedNet &n, const float *cams) {
+            return [&, cams](OpArr<2> (&views)[NB]) {
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) {
+                    const int g = (pass * kFusedWaves + wave) * NB + nb;
+                    const float *dir = a.dir + 3 * (g < n_blocks ? g / a.bpr : 0);
+                    float dv[4] = {0.f, 0.f, 0.f, 0.f};
+                    zest_view_dir(dir, n.w2cs ? cams : nullptr, dv);
+                    encode_pe_operand<3, 4, 2>(dv, half, views[nb]);
+                }
+            };
+        };
         {
-            OpArr<2> views_s[NB];
             OpArr<4> pts_s[NB];
             OpArr<NT_FEAT_S> feat_s[NB];
 #pragma unroll
@@ -225,16 +258,18 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves / 4) void fused_block
                 int g;
                 const float *dir;
                 fetch(pass, nb, b, g, dir);
-                float dv[4] = {0.f, 0.f, 0.f, 0.f};
-                zest_view_dir(dir, a.st.w2cs ? cams_s : nullptr, dv);
-                encode_pe_operand<3, 4, 2>(dv, half, views_s[nb]);
+#ifdef ZEST_EXPERIMENT_NO_ENCODE        // timing experiment only
+#pragma unroll
+                for (int t = 0; t < 4; t++) pts_s[nb].t[t] = bf16x8{(short)lane, 1, 2, 3, 4, 5, 6, 7};
+#else
                 encode_pe_operand<3, 10, 4>(b.x, half, pts_s[nb]);
+#endif
                 if constexpr (MOD_S) encode_feat_operand<NT_FEAT_S>(a.st, cams_s, b.x, b.pw, half, b.valid, feat_s[nb]);
             }
-            engine_forward<NB, 4, MOD_S, NT_FEAT_S>(tiles, unit, a.st.v2 != 0, pts_s, feat_s, views_s, head_s, rgb_s);
+            engine_forward<NB, 4, MOD_S, NT_FEAT_S>(tiles, unit, a.st.v2 != 0, pts_s, feat_s,
+                                                    views_of(a.st, cams_s), head_s, rgb_s);
         }
         if (DYN) {
-            OpArr<2> views_d[NB];
             OpArr<6> pts_d[NB];
             OpArr<NT_FEAT_D> feat_d[NB];
 #pragma unroll
@@ -243,13 +278,11 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves / 4) void fused_block
                 int g;
                 const float *dir;
                 fetch(pass, nb, b, g, dir);
-                float dv[4] = {0.f, 0.f, 0.f, 0.f};
-                zest_view_dir(dir, a.dy.w2cs ? cams_d : nullptr, dv);
-                encode_pe_operand<3, 4, 2>(dv, half, views_d[nb]);
                 encode_pe_operand<4, 10, 6>(b.x, half, pts_d[nb]);
                 if constexpr (MOD_D) encode_feat_operand<NT_FEAT_D>(a.dy, cams_d, b.x, b.pw, half, b.valid, feat_d[nb]);
             }
-            engine_forward<NB, 6, MOD_D, NT_FEAT_D>(tiles, unit, false, pts_d, feat_d, views_d, head_d, rgb_d);
+            engine_forward<NB, 6, MOD_D, NT_FEAT_D>(tiles, unit, false, pts_d, feat_d,
+                                                    views_of(a.dy, cams_d), head_d, rgb_d);
         }
         // ---- per-block compositing on lane half 0 (rgb tile rows 0-2, head tile rows 0,1)
 #pragma unroll
@@ -310,13 +343,15 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves / 4) void fused_block
                            dim3(kFusedWaves * 64), 0, stream, a);                                \
         ZEST_RETURN_LAUNCH("zest_render_fused_fwd(" #tag ")");                                   \
     }                                                                                            \
+    int fused_wg_per_cu_##tag() { return ZEST_FUSED_WG_PER_CU; }                                 \
     int fused_units_##tag(int which) {                                                           \
         return which == 0 ? stream_units(4, NTS) : (DYN ? stream_units(6, NTD) : 0);             \
     }
 
-#define ZEST_FUSED_DECL(tag)                                                  \
+#define ZEST_FUSED_DECL(tag)                                                    \
     int fused_launch_##tag(const FusedArgs &a, int blocks, hipStream_t stream); \
-    int fused_units_##tag(int which);
+    int fused_units_##tag(int which);                                           \
+    int fused_wg_per_cu_##tag();
 ZEST_FUSED_DECL(s0)
 ZEST_FUSED_DECL(s2)
 ZEST_FUSED_DECL(s3)

@@ -120,7 +120,7 @@ extern "C" int zest_render_fused_fwd(const float *ndc, const float *pts, const f
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         cus = 256;
     const int n_pass = zest_div_up((long long)R * a.bpr, zest::kFusedWaves * zest::kFusedNB);
-    const int blocks = n_pass < cus ? n_pass : cus;                 // one workgroup per CU
+    int blocks = cus;                                               // set per variant below
     hipStream_t st = (hipStream_t)stream;
     const int key = (dyn ? 100 : 0) + nts * 10 + ntd;
     int rc = -1;
@@ -129,6 +129,8 @@ extern "C" int zest_render_fused_fwd(const float *ndc, const float *pts, const f
         ZEST_CHECK_ARG(zest::fused_units_##tag(0) == units_s && zest::fused_units_##tag(1) == units_d, \
                        "zest_render_fused_fwd: packed stream is %d+%d units, kernel expects %d+%d",  \
                        units_s, units_d, zest::fused_units_##tag(0), zest::fused_units_##tag(1));    \
+        blocks = cus * zest::fused_wg_per_cu_##tag();                                            \
+        if (n_pass < blocks) blocks = n_pass;                                                    \
         rc = zest::fused_launch_##tag(a, blocks, st);                                            \
         break;
     switch (key) {

@@ -43,7 +43,6 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void mlp_bf16_kernel(
     if (m_base >= M) return;                       // wave-uniform
     OpArr<NT_PTS> pts[NB];
     OpArr<NT_FEAT> feat[NB];
-    OpArr<2> views[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) {
         const long long m = m_base + 32 * nb + col;
@@ -51,12 +50,19 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void mlp_bf16_kernel(
         const float *xrow = x + (size_t)(valid ? m : 0) * C_in;
         load_operand<NT_PTS>(xrow, valid, half, maps.pts, pts[nb]);
         if (MOD) load_operand<NT_FEAT>(xrow + P, valid, half, maps.feat, feat[nb]);
-        load_operand<2>(xrow + P + F, valid, half, maps.views, views[nb]);
     }
+    auto views_fn = [&](OpArr<2> (&views)[NB]) {
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) {
+            const long long m = m_base + 32 * nb + col;
+            const bool valid = m < M;
+            load_operand<2>(x + (size_t)(valid ? m : 0) * C_in + P + F, valid, half, maps.views, views[nb]);
+        }
+    };
     f32x16 headt[NB], rgbt[NB];
     GlobalTiles gt{(gptr_u4)tiles, lane, half};
     int unit = 0;
-    engine_forward<NB, NT_PTS, MOD, NT_FEAT>(gt, unit, v2 != 0, pts, feat, views, headt, rgbt);
+    engine_forward<NB, NT_PTS, MOD, NT_FEAT>(gt, unit, v2 != 0, pts, feat, views_fn, headt, rgbt);
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) {
         const long long m = m_base + 32 * nb + col;

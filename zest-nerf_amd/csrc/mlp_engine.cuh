@@ -70,8 +70,13 @@ struct GlobalTiles {
 // read by anyone - and issues its share of chunk c+kAhead into the slot that frees.  The
 // stream length is a multiple of the ring size, so unit u always sits at ring offset
 // u % kRingUnits and passes follow each other without draining the ring.
-constexpr int kChunk = 16, kSlots = 8, kRingUnits = kChunk * kSlots, kAhead = 4;
-static_assert(kRingUnits == kStreamAlign, "stream padding must equal the ring size");
+#ifndef ZEST_CHUNK
+#define ZEST_CHUNK 16      // units per chunk (one rendezvous per chunk)
+#define ZEST_SLOTS 8       // chunks in the ring
+#define ZEST_AHEAD 4       // chunks of DMA kept in flight
+#endif
+constexpr int kChunk = ZEST_CHUNK, kSlots = ZEST_SLOTS, kRingUnits = kChunk * kSlots, kAhead = ZEST_AHEAD;
+static_assert(kStreamAlign % kRingUnits == 0, "stream padding must be a multiple of the ring size");
 static_assert(kSlots >= kAhead + 1, "a slot is refilled while the previous chunk may still be read");
 
 template <int NW, int UNITS_A, int UNITS_B>
@@ -115,16 +120,24 @@ struct RingTiles {
     __device__ __forceinline__ void enter_chunk(int chunk) const {
         // all but the youngest (kAhead-1)*kPieces of this wave's DMA pieces have landed
         asm volatile("s_waitcnt vmcnt(%0)" ::"i"((kAhead - 1) * kPieces) : "memory");
+#ifndef ZEST_EXPERIMENT_NO_BARRIER      // timing experiment only: results are wrong without it
         __builtin_amdgcn_s_barrier();
+#endif
         asm volatile("" ::: "memory");
+#ifndef ZEST_EXPERIMENT_NO_DMA          // timing experiment only
         issue(chunk + kAhead);
+#endif
     }
     __device__ __forceinline__ void touch(int unit) const {
         if (unit % kChunk == 0) enter_chunk(unit / kChunk);
     }
     __device__ __forceinline__ bf16x8 load(int unit) const {
         touch(unit);
+#ifdef ZEST_EXPERIMENT_NO_LDSREAD       // timing experiment only: one read per chunk
+        const v4u v = *reinterpret_cast<const v4u *>(ring + (unit / kChunk * kChunk % kRingUnits) * 1024 + lane * 16);
+#else
         const v4u v = *reinterpret_cast<const v4u *>(ring + (unit % kRingUnits) * 1024 + lane * 16);
+#endif
         return *reinterpret_cast<const bf16x8 *>(&v);
     }
     __device__ __forceinline__ f32x16 load_bias(int unit, int which) const {
@@ -171,48 +184,70 @@ struct OpArr {              // N operand tiles; N = 0 allowed
     bf16x8 t[N > 0 ? N : 1];
 };
 
+#ifndef ZEST_PREFETCH
+#define ZEST_PREFETCH 3        // weight tiles kept in flight ahead of the MFMA that consumes them
+#endif
+constexpr int kPrefetch = ZEST_PREFETCH;
+
+// What is fetched ahead for one row block: its bias initialisers and its first tiles.
+template <bool MOD>
+struct RowBlockPre {
+    f32x16 bias, mbias;
+    bf16x8 win[kPrefetch];
+};
+
 // One Linear: NJB row blocks over the operand [A (NTA tiles) | B (NTB tiles)].
 //   MOD:  tile is modulated by the feature operand (NTF tiles) with the op's modulation tiles
 //   MODE: 0 = produce operand tiles into `out` (2 per row block), 1 = keep the accumulator of
 //         row block 0 in `keep` (head / rgb tiles)
+// The LDS reads are software-pipelined by hand, in source order, because hipcc leaves them
+// where they are written in a block this large: every tile is requested kPrefetch tiles before
+// the MFMA that uses it, and the NEXT row block's header and first tiles are requested before
+// the CURRENT epilogue, whose ~40 VALU instructions cover their latency.
 template <int NB, int NJB, int NTA, int NTB, bool MOD, int NTF, bool RELU, int MODE, class Tiles>
 __device__ __forceinline__ void engine_layer(const Tiles &tiles, int &unit, bool v2,
                                              const OpArr<NTA> (&opa)[NB], const OpArr<NTB> (&opb)[NB],
                                              const OpArr<NTF> (&opf)[NB], OpArr<16> (&out)[NB],
                                              f32x16 (&keep)[NB]) {
+    constexpr int NM = MOD ? NTF : 0, T = NM + NTA + NTB;       // tiles per row block
+    static_assert(T >= 1, "empty layer");
+    auto preload = [&](RowBlockPre<MOD> &p, int u0) {           // u0: the row block's header unit
+        p.bias = tiles.load_bias(u0, 0);
+        if (MOD) p.mbias = tiles.load_bias(u0, 1);
+#pragma unroll
+        for (int k = 0; k < kPrefetch; k++)
+            if (k < T) p.win[k] = tiles.load(u0 + 1 + k);
+    };
+    RowBlockPre<MOD> pre;
+    preload(pre, unit);
 #pragma unroll
     for (int jb = 0; jb < NJB; jb++) {
+        const int u0 = unit;
         f32x16 acc[NB], macc[NB];
-        const int hdr = unit++;
-        const f32x16 b0 = tiles.load_bias(hdr, 0);
+        bf16x8 win[kPrefetch];
 #pragma unroll
-        for (int nb = 0; nb < NB; nb++) acc[nb] = b0;
-        if (MOD) {
-            const f32x16 m0 = tiles.load_bias(hdr, 1);
+        for (int k = 0; k < kPrefetch; k++) win[k] = pre.win[k];
 #pragma unroll
-            for (int nb = 0; nb < NB; nb++) macc[nb] = m0;
+        for (int nb = 0; nb < NB; nb++) {
+            acc[nb] = pre.bias;
+            if (MOD) macc[nb] = pre.mbias;
+        }
 #pragma unroll
-            for (int k = 0; k < NTF; k++) {
-                const bf16x8 a = tiles.load(unit++);
+        for (int k = 0; k < T; k++) {
+            const bf16x8 a = win[k % kPrefetch];
 #pragma unroll
-                for (int nb = 0; nb < NB; nb++)
-                    macc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, opf[nb].t[k], macc[nb], 0, 0, 0);
+            for (int nb = 0; nb < NB; nb++) {
+                if (k < NM)
+                    macc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, opf[nb].t[k < NM ? k : 0], macc[nb], 0, 0, 0);
+                else if (k < NM + NTA)
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, opa[nb].t[(k >= NM && k < NM + NTA) ? k - NM : 0], acc[nb], 0, 0, 0);
+                else
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, opb[nb].t[k >= NM + NTA ? k - NM - NTA : 0], acc[nb], 0, 0, 0);
             }
+            if (k + kPrefetch < T) win[k % kPrefetch] = tiles.load(u0 + 1 + k + kPrefetch);
         }
-#pragma unroll
-        for (int k = 0; k < NTA; k++) {
-            const bf16x8 a = tiles.load(unit++);
-#pragma unroll
-            for (int nb = 0; nb < NB; nb++)
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, opa[nb].t[k], acc[nb], 0, 0, 0);
-        }
-#pragma unroll
-        for (int k = 0; k < NTB; k++) {
-            const bf16x8 a = tiles.load(unit++);
-#pragma unroll
-            for (int nb = 0; nb < NB; nb++)
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, opb[nb].t[k], acc[nb], 0, 0, 0);
-        }
+        unit = u0 + 1 + T;
+        if (jb + 1 < NJB) preload(pre, unit);                   // in flight during the epilogue
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) {
             f32x16 v = acc[nb];
@@ -229,21 +264,19 @@ __device__ __forceinline__ void engine_layer(const Tiles &tiles, int &unit, bool
             else if (jb == 0)
                 keep[nb] = v;
         }
-#ifdef ZEST_SCHED_FENCE
-        __builtin_amdgcn_sched_barrier(0);
-#endif
     }
 }
 
 // The whole network for NB column blocks, reading the stream from unit `unit` on (advanced to
-// the end of the net's padded stream).  pts/feat/views: encoder operands in plan slot order.
-// Results: head tile (row 0 alpha, rows 1.. extra heads) and rgb tile (rows 0-2), raw.
-template <int NB, int NT_PTS, bool MOD, int NT_FEAT, class Tiles>
+// the end of the net's padded stream).  pts/feat: encoder operands in plan slot order;
+// `views_fn(views)` builds the direction operand when it is first needed (op 10) so that it does
+// not occupy registers through the trunk.  Results: head tile (row 0 alpha, rows 1.. extra
+// heads) and rgb tile (rows 0-2), raw.
+template <int NB, int NT_PTS, bool MOD, int NT_FEAT, class Tiles, class ViewsFn>
 __device__ __forceinline__ void engine_forward(const Tiles &tiles, int &unit, bool v2,
                                                const OpArr<NT_PTS> (&pts)[NB],
-                                               const OpArr<NT_FEAT> (&feat)[NB],
-                                               const OpArr<2> (&views)[NB], f32x16 (&head)[NB],
-                                               f32x16 (&rgb)[NB]) {
+                                               const OpArr<NT_FEAT> (&feat)[NB], ViewsFn views_fn,
+                                               f32x16 (&head)[NB], f32x16 (&rgb)[NB]) {
     OpArr<16> hA[NB], hB[NB];
     OpArr<0> none[NB];
     f32x16 unused[NB];
@@ -259,6 +292,8 @@ __device__ __forceinline__ void engine_forward(const Tiles &tiles, int &unit, bo
     // trunk output in hB
     engine_layer<NB, 1, 16, 0, false, NT_FEAT, false, 1>(tiles, unit, v2, hB, none, feat, hA, head);
     engine_layer<NB, 8, 16, 0, false, NT_FEAT, false, 0>(tiles, unit, v2, hB, none, feat, hA, unused);
+    OpArr<2> views[NB];
+    views_fn(views);
     engine_layer<NB, 4, 16, 2, false, NT_FEAT, true, 0>(tiles, unit, v2, hA, views, feat, hB, unused);
     // rgb: 128 hidden features = first 8 tiles of hB
     OpArr<8> h128[NB];

@@ -12,7 +12,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzest_hip.so")
+# ZEST_HIP_LIB selects an experiment build (build_hip.py --tag); default is the product library
+LIB_PATH = os.environ.get("ZEST_HIP_LIB") or os.path.join(_HERE, "libzest_hip.so")
 
 PREC_F32, PREC_BF16 = 0, 1
 HEAD_NONE, HEAD_BLEND, HEAD_DYNAMIC = 0, 1, 2

@@ -39,6 +39,7 @@ struct FusedArgs {
     int bpr;                              // 32-sample blocks per ray = ceil(S / 32)
     float *partials;                      // [R*bpr, kPartialFloats] workspace
     float *out;                           // [R,16]
+    unsigned long long *stamps;           // diagnostic builds (ZEST_STAMPS): 8 u64 per wave, else null
 };
 
 __device__ __forceinline__ bf16x8 pack_tile(const float (&v)[8]) {
@@ -47,47 +48,38 @@ __device__ __forceinline__ bf16x8 pack_tile(const float (&v)[8]) {
     return *reinterpret_cast<bf16x8 *>(&a);
 }
 
-// swap the two 32-lane halves of a register (v_permlane32_swap, no LDS)
-__device__ __forceinline__ float swap_halves(float v, int half) {
-    const unsigned u = __float_as_uint(v);
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __uint_as_float(half ? r[0] : r[1]);
-}
-
 // Positional-encoding operand for C coordinates and L bands in plan slot order
 // (mlp_plan.hip pe_map_acc): slot q < L*C holds sin (half 0) / cos (half 1) of
 // 2^(q/C) * x[q%C]; then the raw coordinates two per slot; zero padding after that.
-// Both lane halves own the same sample, so they split the arguments: for the pair (q, q+1)
-// half 0 evaluates sincos of argument q, half 1 of q+1, and one half-swap hands the partner
-// the value it needs (cos q to half 1, sin q+1 to half 0): L*C/2 sincos per lane, not L*C.
+// The engine rounds operands to bf16 (8 significant bits), so the hardware sine is used:
+// v_sin_f32 takes revolutions, cos is sin shifted by a quarter revolution, and the range
+// reduction is one v_fract.  Its absolute error (~1e-6) plus the rounding of arg/(2 pi)
+// (3e-5 rad at 2^9 x) is 1/50 of a bf16 ulp; the fp32 per-op path (encode.hip) keeps the
+// accurate sincos.
 template <int C, int L, int NT>
 __device__ __forceinline__ void encode_pe_operand(const float (&x)[4], int half, OpArr<NT> &op) {
-    static_assert((L * C) % 2 == 0 && L * C + (C + 1) / 2 <= NT * 8, "slot layout");
-    float val[NT * 8];
+    static_assert(L * C + (C + 1) / 2 <= NT * 8, "slot layout");
+    const float quarter = half ? 0.25f : 0.0f;
+    float rev[C];
 #pragma unroll
-    for (int q = L * C; q < NT * 8; q++) {
-        const int p = q - L * C;
-        val[q] = 0.0f;
-        if (p < (C + 1) / 2) {
-            const float lo = x[2 * p], hi = (2 * p + 1 < C) ? x[2 * p + 1] : 0.0f;
-            val[q] = half ? hi : lo;
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < L * C; q += 2) {
-        const float a0 = x[q % C] * (float)(1 << (q / C));
-        const float a1 = x[(q + 1) % C] * (float)(1 << ((q + 1) / C));
-        float s, c;
-        zest_sincos(half ? a1 : a0, &s, &c);
-        const float other = swap_halves(half ? s : c, half);   // half 0 gets sin(a1), half 1 cos(a0)
-        val[q] = half ? other : s;
-        val[q + 1] = half ? c : other;
-    }
+    for (int c = 0; c < C; c++) rev[c] = x[c] * 0.15915494309189535f;      // revolutions at band 0
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; e++) v[e] = val[8 * t + e];
+        for (int e = 0; e < 8; e++) {
+            const int q = 8 * t + e;
+            if (q < L * C) {
+                const float r = fmaf(rev[q % C], (float)(1 << (q / C)), quarter);
+                v[e] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(r));
+            } else if (q < L * C + (C + 1) / 2) {
+                const int p = q - L * C;
+                const float lo = x[2 * p], hi = (2 * p + 1 < C) ? x[2 * p + 1] : 0.0f;
+                v[e] = half ? hi : lo;
+            } else {
+                v[e] = 0.0f;
+            }
+        }
         op.t[t] = pack_tile(v);
     }
 }
@@ -102,7 +94,9 @@ __device__ __forceinline__ void encode_feat_operand(const FusedNet &n, const flo
 #pragma unroll
     for (int i = 0; i < NT * 8; i++) v[i] = 0.0f;
     if (valid) {
-        // trilinear lookup of this half's four channels
+        // Trilinear lookup of this half's four channels.  Branch-free: out-of-volume corners
+        // read a clamped address with weight 0, so all eight 16-byte loads are in flight
+        // together instead of one divergent branch (and one memory round trip) per corner.
         {
             float fx = zest_unnorm(ndc[0], n.Wv), fy = zest_unnorm(ndc[1], n.Hv), fz = zest_unnorm(ndc[2], n.D);
             fx = fminf(fmaxf(fx, -2.0f), (float)n.Wv + 1.0f);
@@ -111,36 +105,43 @@ __device__ __forceinline__ void encode_feat_operand(const FusedNet &n, const flo
             const float x0f = floorf(fx), y0f = floorf(fy), z0f = floorf(fz);
             const float tx = fx - x0f, ty = fy - y0f, tz = fz - z0f;
             const int x0 = (int)x0f, y0 = (int)y0f, z0 = (int)z0f;
+            float4 tap[8];
+            float wgt[8];
 #pragma unroll
             for (int c = 0; c < 8; c++) {
                 const int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
                 const int xi = x0 + dx, yi = y0 + dy, zi = z0 + dz;
-                const float w = (dx ? tx : 1.0f - tx) * (dy ? ty : 1.0f - ty) * (dz ? tz : 1.0f - tz);
-                if ((unsigned)xi < (unsigned)n.Wv && (unsigned)yi < (unsigned)n.Hv &&
-                    (unsigned)zi < (unsigned)n.D) {
-                    const float4 a = n.vol[2 * (((size_t)zi * n.Hv + yi) * n.Wv + xi) + half];
-                    v[0] = fmaf(w, a.x, v[0]), v[1] = fmaf(w, a.y, v[1]);
-                    v[2] = fmaf(w, a.z, v[2]), v[3] = fmaf(w, a.w, v[3]);
-                }
+                const bool ok = (unsigned)xi < (unsigned)n.Wv && (unsigned)yi < (unsigned)n.Hv &&
+                                (unsigned)zi < (unsigned)n.D;
+                const int xc = min(max(xi, 0), n.Wv - 1), yc = min(max(yi, 0), n.Hv - 1),
+                          zc = min(max(zi, 0), n.D - 1);
+                wgt[c] = ok ? (dx ? tx : 1.0f - tx) * (dy ? ty : 1.0f - ty) * (dz ? tz : 1.0f - tz) : 0.0f;
+                tap[c] = n.vol[2 * (((size_t)zc * n.Hv + yc) * n.Wv + xc) + half];
+            }
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                v[0] = fmaf(wgt[c], tap[c].x, v[0]), v[1] = fmaf(wgt[c], tap[c].y, v[1]);
+                v[2] = fmaf(wgt[c], tap[c].z, v[2]), v[3] = fmaf(wgt[c], tap[c].w, v[3]);
             }
         }
+        // source views 2p+half: the view index beyond V is clamped and its result discarded
 #pragma unroll
         for (int p = 0; p < (NT * 8 - 4) / 4; p++) {
             const int view = 2 * p + half;
-            if (view < n.V) {
-                ZestCam cam;
-                const float *cl = cams_lds + view * kCamStride;
+            const int vc = view < n.V ? view : n.V - 1;
+            ZestCam cam;
+            const float *cl = cams_lds + vc * kCamStride;
 #pragma unroll
-                for (int i = 0; i < 3; i++) {
+            for (int i = 0; i < 3; i++) {
 #pragma unroll
-                    for (int j = 0; j < 4; j++) cam.r[i][j] = cl[4 * i + j];
+                for (int j = 0; j < 4; j++) cam.r[i][j] = cl[4 * i + j];
 #pragma unroll
-                    for (int j = 0; j < 3; j++) cam.k[i][j] = cl[12 + 3 * i + j];
-                }
-                const float4 o = zest_color_tap(n.imgs + (size_t)view * n.H * n.W, n.H, n.W, cam,
-                                                pw[0], pw[1], pw[2]);
-                v[4 + 4 * p] = o.x, v[5 + 4 * p] = o.y, v[6 + 4 * p] = o.z, v[7 + 4 * p] = o.w;
+                for (int j = 0; j < 3; j++) cam.k[i][j] = cl[12 + 3 * i + j];
             }
+            const float4 o = zest_color_tap(n.imgs + (size_t)vc * n.H * n.W, n.H, n.W, cam, pw[0], pw[1], pw[2]);
+            const bool on = view < n.V;
+            v[4 + 4 * p] = on ? o.x : 0.f, v[5 + 4 * p] = on ? o.y : 0.f;
+            v[6 + 4 * p] = on ? o.z : 0.f, v[7 + 4 * p] = on ? o.w : 0.f;
         }
     }
 #pragma unroll
@@ -162,15 +163,6 @@ __device__ __forceinline__ void stage_cams(const FusedNet &n, float *lds) {
         else if (k < 21 && n.intr) val = n.intr[9 * v + (k - 12)];
         lds[i] = val;
     }
-}
-
-// exclusive product over the 32 lanes of a half, given each lane's factor
-__device__ __forceinline__ float excl_scan32(float f, int col, float *total) {
-    const float incl = seg_scan_mul<32>(f, col);
-    float ex = __shfl_up(incl, 1, 32);
-    if (col == 0) ex = 1.0f;
-    *total = __shfl(incl, 31, 32);
-    return ex;
 }
 
 #ifndef ZEST_FUSED_WAVES
@@ -199,8 +191,11 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
     constexpr int NB = kFusedNB;
     constexpr int UNITS_S = stream_units(4, NT_FEAT_S), UNITS_D = DYN ? stream_units(6, NT_FEAT_D) : 0;
     using Ring = RingTiles<kFusedWaves, UNITS_S, UNITS_D>;
-    __shared__ __attribute__((aligned(16))) char lds[kRingUnits * 1024 + 2 * kMaxViews * kCamStride * 4];
+    // LDS: weight ring | cameras of both nets | per-lane (z, dist) of the pass's samples
+    __shared__ __attribute__((aligned(16))) char lds[kRingUnits * 1024 + 2 * kMaxViews * kCamStride * 4 +
+                                                     kFusedWaves * NB * 32 * 8];
     float *cams_s = reinterpret_cast<float *>(lds + kRingUnits * 1024), *cams_d = cams_s + kMaxViews * kCamStride;
+    float2 *zd_lds = reinterpret_cast<float2 *>(cams_d + kMaxViews * kCamStride);
     stage_cams(a.st, cams_s);
     if (DYN) stage_cams(a.dy, cams_d);
     __syncthreads();
@@ -208,7 +203,9 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
     const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const Ring tiles{lds, (gptr_u4)a.st.tiles, (gptr_u4)a.dy.tiles, lane, half, wave,
-                     (unsigned)(wave * Ring::kPieces * 64 + lane) * 16u};
+                     (unsigned)(wave * Ring::kPieces * 64 + lane) * 16u,
+                     (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds +
+                         (unsigned)wave * Ring::kPieces * 1024u};
     tiles.prologue();
 
     const int n_blocks = a.R * a.bpr;
@@ -233,7 +230,18 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
             b.dist = ((s + 1 < a.S) ? (zr[s + 1] - b.zz) : 1e10f) * dnorm;
         }
     };
+#ifdef ZEST_STAMPS
+    unsigned long long st_enc = 0, st_eng = 0, st_comp = 0, st_n = 0;
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#define ZEST_STAMP(var) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); var += t_ - st_last; st_last = t_; } while (0)
+#else
+#define ZEST_STAMP(var) do {} while (0)
+#endif
     for (int pass = blockIdx.x; pass < n_pass; pass += gridDim.x) {
+#ifdef ZEST_STAMPS
+        unsigned long long st_last = __builtin_amdgcn_s_memtime();
+        st_n++;
+#endif
         int unit = 0;
         f32x16 head_s[NB], rgb_s[NB], head_d[NB], rgb_d[NB];
         // direction operand of net `n`, built when the engine reaches the view layer
@@ -258,6 +266,9 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
                 int g;
                 const float *dir;
                 fetch(pass, nb, b, g, dir);
+                // compositing needs z and the sample spacing after the engine: park them in LDS so
+                // that phase issues no global load (a vmcnt wait there would drain the weight DMA)
+                if (half == 0) zd_lds[(wave * NB + nb) * 32 + col] = make_float2(b.zz, b.valid ? b.dist : -1.0f);
 #ifdef ZEST_EXPERIMENT_NO_ENCODE        // timing experiment only
 #pragma unroll
                 for (int t = 0; t < 4; t++) pts_s[nb].t[t] = bf16x8{(short)lane, 1, 2, 3, 4, 5, 6, 7};
@@ -266,8 +277,10 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
 #endif
                 if constexpr (MOD_S) encode_feat_operand<NT_FEAT_S>(a.st, cams_s, b.x, b.pw, half, b.valid, feat_s[nb]);
             }
+            ZEST_STAMP(st_enc);
             engine_forward<NB, 4, MOD_S, NT_FEAT_S>(tiles, unit, a.st.v2 != 0, pts_s, feat_s,
                                                     views_of(a.st, cams_s), head_s, rgb_s);
+            ZEST_STAMP(st_eng);
         }
         if (DYN) {
             OpArr<6> pts_d[NB];
@@ -281,16 +294,21 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
                 encode_pe_operand<4, 10, 6>(b.x, half, pts_d[nb]);
                 if constexpr (MOD_D) encode_feat_operand<NT_FEAT_D>(a.dy, cams_d, b.x, b.pw, half, b.valid, feat_d[nb]);
             }
+            ZEST_STAMP(st_enc);
             engine_forward<NB, 6, MOD_D, NT_FEAT_D>(tiles, unit, false, pts_d, feat_d,
                                                     views_of(a.dy, cams_d), head_d, rgb_d);
+            ZEST_STAMP(st_eng);
         }
         // ---- per-block compositing on lane half 0 (rgb tile rows 0-2, head tile rows 0,1)
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) {
             BlockSamples b;
-            int gidx;
-            const float *dir_unused;
-            fetch(pass, nb, b, gidx, dir_unused);
+            const int g_ = (pass * kFusedWaves + wave) * NB + nb;
+            const int gidx = g_ < n_blocks ? g_ : -1;
+            {
+                const float2 zd = zd_lds[(wave * NB + nb) * 32 + col];
+                b.zz = zd.x, b.dist = fmaxf(zd.y, 0.0f), b.valid = zd.y >= 0.0f;
+            }
             float cr = rgb_s[nb][0], cg = rgb_s[nb][1], cb = rgb_s[nb][2], sg = head_s[nb][0];
             if (a.st.v2) {   // 'v2' nets activate inside the network; the compositor does it again
                 cr = zest_sigmoid(cr), cg = zest_sigmoid(cg), cb = zest_sigmoid(cb), sg = fmaxf(sg, 0.f);
@@ -302,10 +320,10 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
             for (int i = 0; i < kPartialFloats; i++) rec[i] = 0.f;
             {
                 float tot;
-                const float w = al_s * excl_scan32(1.0f - al_s + 1e-10f, col, &tot);
+                const float w = al_s * lower_half_excl_prod(1.0f - al_s + 1e-10f, col, &tot);
                 rec[0] = tot;
-                rec[1] = half_sum(w * cr), rec[2] = half_sum(w * cg), rec[3] = half_sum(w * cb);
-                rec[4] = half_sum(w * b.zz), rec[5] = half_sum(w);
+                rec[1] = lower_half_sum(w * cr), rec[2] = lower_half_sum(w * cg), rec[3] = lower_half_sum(w * cb);
+                rec[4] = lower_half_sum(w * b.zz), rec[5] = lower_half_sum(w);
             }
             if (DYN) {
                 const float blend = zest_sigmoid(head_s[nb][1]);
@@ -314,16 +332,16 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
                 const float a_fg = b.valid ? 1.0f - expf(-fmaxf(head_d[nb][0], 0.f) * b.dist) : 0.0f;
                 const float a_d = a_fg * blend, a_st = al_s * (1.0f - blend);
                 float tot_b, tot_f;
-                const float Tb = excl_scan32((1.0f - a_d) * (1.0f - a_st) + 1e-10f, col, &tot_b);
-                const float wf = a_fg * excl_scan32(1.0f - a_fg + 1e-10f, col, &tot_f);
+                const float Tb = lower_half_excl_prod((1.0f - a_d) * (1.0f - a_st) + 1e-10f, col, &tot_b);
+                const float wf = a_fg * lower_half_excl_prod(1.0f - a_fg + 1e-10f, col, &tot_f);
                 const float wd = Tb * a_d, ws = Tb * a_st;
                 rec[6] = tot_b;
-                rec[7] = half_sum(wd * er + ws * cr), rec[8] = half_sum(wd * eg + ws * cg);
-                rec[9] = half_sum(wd * eb + ws * cb), rec[10] = half_sum((wd + ws) * b.zz);
-                rec[11] = half_sum(wd);
+                rec[7] = lower_half_sum(wd * er + ws * cr), rec[8] = lower_half_sum(wd * eg + ws * cg);
+                rec[9] = lower_half_sum(wd * eb + ws * cb), rec[10] = lower_half_sum((wd + ws) * b.zz);
+                rec[11] = lower_half_sum(wd);
                 rec[12] = tot_f;
-                rec[13] = half_sum(wf * er), rec[14] = half_sum(wf * eg), rec[15] = half_sum(wf * eb);
-                rec[16] = half_sum(wf * b.zz);
+                rec[13] = lower_half_sum(wf * er), rec[14] = lower_half_sum(wf * eg), rec[15] = lower_half_sum(wf * eb);
+                rec[16] = lower_half_sum(wf * b.zz);
             }
             if (lane == 0 && gidx >= 0) {
                 float4 *o = reinterpret_cast<float4 *>(a.partials + (size_t)gidx * kPartialFloats);
@@ -332,8 +350,16 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
                     o[i] = make_float4(rec[4 * i], rec[4 * i + 1], rec[4 * i + 2], rec[4 * i + 3]);
             }
         }
+        ZEST_STAMP(st_comp);
     }
     tiles.drain();
+#ifdef ZEST_STAMPS
+    if (a.stamps && lane == 0) {
+        unsigned long long *o = a.stamps + (size_t)(blockIdx.x * kFusedWaves + wave) * 8;
+        o[0] = __builtin_amdgcn_s_memtime() - st_t0, o[1] = st_enc, o[2] = st_eng, o[3] = st_comp;
+        o[4] = tiles.t_wait, o[5] = tiles.t_issue, o[6] = __builtin_amdgcn_s_memrealtime() - st_r0, o[7] = st_n;
+    }
+#endif
 }
 
 // one translation unit per variant (fused_*.hip) so they compile in parallel

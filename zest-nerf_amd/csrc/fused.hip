@@ -75,9 +75,15 @@ bool fill_net(const zest_mlp_desc *d, const void *packed, const zest_view_set *v
 
 }  // namespace
 
+#ifdef ZEST_STAMPS
+constexpr size_t kStampBytes = 1024 * 8 * 8 * 8;       // diagnostic builds: 8 u64 per wave, <= 8192 waves
+#else
+constexpr size_t kStampBytes = 0;
+#endif
+
 extern "C" size_t zest_render_fused_workspace(int R, int S) {
-    if (R <= 0 || S <= 0) return 16;
-    return (size_t)R * ((S + 31) / 32) * zest::kPartialFloats * sizeof(float);
+    if (R <= 0 || S <= 0) return 16 + kStampBytes;
+    return (size_t)R * ((S + 31) / 32) * zest::kPartialFloats * sizeof(float) + kStampBytes;
 }
 
 extern "C" int zest_render_fused_fwd(const float *ndc, const float *pts, const float *z,
@@ -101,6 +107,9 @@ extern "C" int zest_render_fused_fwd(const float *ndc, const float *pts, const f
     a.ndc = ndc, a.pts = pts, a.z = z, a.dir = rays_dir, a.R = R, a.S = S;
     a.frame_idx = frame_idx, a.white_bkgd = white_bkgd, a.out = out;
     a.bpr = (S + 31) / 32, a.partials = (float *)workspace;
+#ifdef ZEST_STAMPS
+    a.stamps = (unsigned long long *)((char *)workspace + (size_t)R * a.bpr * zest::kPartialFloats * sizeof(float));
+#endif
     const char *err = nullptr;
     int nts = 0, ntd = 0, units_s = 0, units_d = 0;
     ZEST_CHECK_ARG(fill_net(desc_static, packed_static, views_static, 63, &a.st, &nts, &units_s, &err),

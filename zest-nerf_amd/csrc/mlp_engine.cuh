@@ -88,44 +88,64 @@ struct RingTiles {
     gptr_u4 src_a, src_b;  // the two nets' streams (src_b unused when UNITS_B == 0)
     int lane, half, wave;  // wave: provably uniform (readfirstlane)
     unsigned voff;         // (wave * kPieces * 64 + lane) * 16: this lane's byte offset in a chunk
+    unsigned lds_wave_base; // LDS byte address of the ring + wave * kPieces * 1024
+#ifdef ZEST_STAMPS         // diagnostic build: cycles spent in enter_chunk (DMA wait + barrier + issue)
+    mutable unsigned long long t_wait = 0, t_issue = 0;
+#endif
 
     // LDS-DMA of this wave's pieces of a chunk.  Issued through inline asm so that only the
     // counted waits in enter_chunk govern it: hipcc would otherwise drain vmcnt(0) in front of
     // every ds_read it cannot prove disjoint from the DMA destination
-    // (cdna_hip_programming.md 5.7; M0 = LDS destination, restored afterwards).  Addressing
-    // is scalar base + 32-bit lane offset: the per-chunk part stays in SGPRs, so there are no
-    // per-chunk address VGPRs for the compiler to hoist out of the pass loop and spill.
+    // (cdna_hip_programming.md 5.7).  M0 = this wave's LDS destination; the instruction offset
+    // advances both the global source and the LDS destination, so one M0 write serves all of
+    // the wave's pieces.  M0 is not restored: hipcc keeps nothing live in it across an asm
+    // statement that declares it clobbered.  Addressing is scalar base + 32-bit lane offset,
+    // and the chunk's byte offset is made opaque so the 64-bit adds stay here instead of being
+    // hoisted out of the pass loop for all chunks at once (which spills SGPRs to VGPR lanes).
     __device__ __forceinline__ void issue(int chunk) const {      // chunk: compile-time after unrolling
         const int c = chunk % kChunks;
-        const __attribute__((address_space(1))) char *src =
-            c < kChunksA ? (const __attribute__((address_space(1))) char *)src_a + (size_t)c * kChunk * 1024
-                         : (const __attribute__((address_space(1))) char *)src_b + (size_t)(c - kChunksA) * kChunk * 1024;
-        const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)ring;
-#pragma unroll
-        for (int i = 0; i < kPieces; i++) {
-            const unsigned dst = lds_base + ((c % kSlots) * kChunk + wave * kPieces + i) * 1024;
-            const __attribute__((address_space(1))) char *sb = src + i * 1024;
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                         "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep)
-                         : "v"(voff), "s"(sb), "s"(dst)
-                         : "memory");
-        }
+        unsigned off = (unsigned)((c < kChunksA ? c : c - kChunksA) * kChunk * 1024);
+        asm volatile("" : "+s"(off));
+        const __attribute__((address_space(1))) char *sb =
+            (const __attribute__((address_space(1))) char *)(c < kChunksA ? src_a : src_b) + off;
+        const unsigned dst = lds_wave_base + (c % kSlots) * kChunk * 1024;
+        static_assert(kPieces == 1 || kPieces == 2 || kPieces == 4, "pieces per wave");
+        if (kPieces == 1)
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                         :: "v"(voff), "s"(sb), "s"(dst) : "memory", "m0");
+        else if (kPieces == 2)
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\t"
+                         "global_load_lds_dwordx4 %0, %1 offset:1024"
+                         :: "v"(voff), "s"(sb), "s"(dst) : "memory", "m0");
+        else
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\t"
+                         "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                         "global_load_lds_dwordx4 %0, %1 offset:2048\n\t"
+                         "global_load_lds_dwordx4 %0, %1 offset:3072"
+                         :: "v"(voff), "s"(sb), "s"(dst) : "memory", "m0");
     }
     __device__ __forceinline__ void prologue() const {
 #pragma unroll
         for (int c = 0; c < kAhead; c++) issue(c);
     }
     __device__ __forceinline__ void enter_chunk(int chunk) const {
+#ifdef ZEST_STAMPS
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
         // all but the youngest (kAhead-1)*kPieces of this wave's DMA pieces have landed
         asm volatile("s_waitcnt vmcnt(%0)" ::"i"((kAhead - 1) * kPieces) : "memory");
 #ifndef ZEST_EXPERIMENT_NO_BARRIER      // timing experiment only: results are wrong without it
         __builtin_amdgcn_s_barrier();
 #endif
         asm volatile("" ::: "memory");
+#ifdef ZEST_STAMPS
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#endif
 #ifndef ZEST_EXPERIMENT_NO_DMA          // timing experiment only
         issue(chunk + kAhead);
+#endif
+#ifdef ZEST_STAMPS
+        t_wait += t1 - t0, t_issue += __builtin_amdgcn_s_memtime() - t1;
 #endif
     }
     __device__ __forceinline__ void touch(int unit) const {

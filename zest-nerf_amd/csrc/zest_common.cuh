@@ -55,6 +55,38 @@ __device__ __forceinline__ float seg_scan_mul(float v, int lane_in_seg) {
     return v;
 }
 
+// ---- DPP forms for a 32-lane half (plain VALU: no LDS round trip per step) --------------------
+// dpp_ctrl: quad_perm[1,0,3,2]=0xB1, quad_perm[2,3,0,1]=0x4E, row_half_mirror=0x141,
+// row_mirror=0x140, row_shr:n=0x110+n, row_bcast:15=0x142, wave_shr:1=0x138
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f(float old, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL,
+                                                       ROW_MASK, 0xF, false));
+}
+
+// sum over lanes 0..31, returned wave-uniform (meaningful for the lower half)
+__device__ __forceinline__ float lower_half_sum(float v) {
+    v += dpp_f<0xB1>(0.f, v);
+    v += dpp_f<0x4E>(0.f, v);
+    v += dpp_f<0x141>(0.f, v);
+    v += dpp_f<0x140>(0.f, v);                 // every lane of a 16-lane row holds the row sum
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16);
+}
+
+// product scan over lanes 0..31: returns the exclusive prefix product for this lane (col =
+// lane & 31; correct for the lower half) and the product of all 32 factors in *total
+__device__ __forceinline__ float lower_half_excl_prod(float f, int col, float *total) {
+    float v = f;
+    v *= dpp_f<0x111>(1.f, v);
+    v *= dpp_f<0x112>(1.f, v);
+    v *= dpp_f<0x114>(1.f, v);
+    v *= dpp_f<0x118>(1.f, v);                 // inclusive within each 16-lane row
+    v *= dpp_f<0x142, 0xA>(1.f, v);            // rows 1 and 3 take the last lane of the row before
+    *total = __builtin_amdgcn_readlane(v, 31);
+    float ex = dpp_f<0x138>(1.f, v);           // shift the wave right by one lane
+    return col == 0 ? 1.0f : ex;
+}
+
 // ---- scalar math ---------------------------------------------------------------------
 __device__ __forceinline__ float zest_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 

@@ -23,8 +23,9 @@ need = int(zest_hip.lib().zest_render_fused_workspace(d.R, d.S))
 ws = torch.zeros(need, dtype=torch.uint8, device="cuda:0")
 orig = zest_hip.render_fused
 zest_hip.render_fused = lambda *a, **k: orig(*a, **dict(k, workspace=ws))
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 2000       # ~0.3 s of sustained load before reading
 with torch.no_grad():
-    for _ in range(20):
+    for _ in range(steps):
         bench.render_step(d)
     torch.cuda.synchronize()
 rec_bytes = d.R * ((d.S + 31) // 32) * 80

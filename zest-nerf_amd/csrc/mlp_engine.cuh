@@ -161,7 +161,7 @@ struct RingTiles {
         return *reinterpret_cast<const bf16x8 *>(&v);
     }
     __device__ __forceinline__ f32x16 load_bias(int unit, int which) const {
-        touch(unit);
+        if (which == 0) touch(unit);          // the modulation block (which = 1) is read right after
         const v4f *b = reinterpret_cast<const v4f *>(ring + (unit % kRingUnits) * 1024 + which * 128 + half * 64);
         return f32x16_from(b[0], b[1], b[2], b[3]);
     }

@@ -64,13 +64,19 @@ __device__ __forceinline__ float dpp_f(float old, float v) {
                                                        ROW_MASK, 0xF, false));
 }
 
+// value of lane `l` as a wave-uniform float (the builtin is int-typed: bit-cast, do not convert)
+template <int L>
+__device__ __forceinline__ float readlane_f(float v) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), L));
+}
+
 // sum over lanes 0..31, returned wave-uniform (meaningful for the lower half)
 __device__ __forceinline__ float lower_half_sum(float v) {
     v += dpp_f<0xB1>(0.f, v);
     v += dpp_f<0x4E>(0.f, v);
     v += dpp_f<0x141>(0.f, v);
     v += dpp_f<0x140>(0.f, v);                 // every lane of a 16-lane row holds the row sum
-    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16);
+    return readlane_f<0>(v) + readlane_f<16>(v);
 }
 
 // product scan over lanes 0..31: returns the exclusive prefix product for this lane (col =
@@ -82,7 +88,7 @@ __device__ __forceinline__ float lower_half_excl_prod(float f, int col, float *t
     v *= dpp_f<0x114>(1.f, v);
     v *= dpp_f<0x118>(1.f, v);                 // inclusive within each 16-lane row
     v *= dpp_f<0x142, 0xA>(1.f, v);            // rows 1 and 3 take the last lane of the row before
-    *total = __builtin_amdgcn_readlane(v, 31);
+    *total = readlane_f<31>(v);
     float ex = dpp_f<0x138>(1.f, v);           // shift the wave right by one lane
     return col == 0 ? 1.0f : ex;
 }

@@ -131,6 +131,25 @@ int zest_encode_fwd(const float *ndc, const float *pts, const float *rays_dir, i
                     const float *w2cs, const float *intrinsics,
                     float *x, void *stream);
 
+/* ---- ray sampling (the step in front of the renderer) -----------------------------
+ * Per-sample part of build_rays_base (reference utils.py:361-387): depth candidates
+ * near*(1-t)+far*t over t = linspace(0,1,S), jittered inside their strata when t_rand [R,S]
+ * is given (the reference's torch.rand draw), points o + z d along the target camera's rays
+ * through pixels (xs, ys) [R], and their coordinates in the reference view's padded volume
+ * (get_ndc_coordinate, utils.py:232-288).  The four camera matrices are HOST pointers
+ * (row-major 3x3 / 4x4).  Outputs: rays_dir [R,3], depth [R,S], pts [R,S,3], ndc [R,S,3]. */
+int zest_build_rays_fwd(const float *xs, const float *ys, const float *t_rand, int R, int S,
+                        const float *k_tgt_host, const float *c2w_tgt_host,
+                        const float *w2c_ref_host, const float *k_ref_host, float near_tgt,
+                        float far_tgt, float near_ref, float far_ref, int pad, int W, int H,
+                        float *rays_dir, float *depth, float *pts, float *ndc, void *stream);
+
+/* get_ndc_coordinate (reference utils.py:232-288): world pts [M,3] -> (u, v, z) normalised by
+ * inv_scale = (inv_w, inv_h) and [near, far] (or inverse depth when lindisp), with the padded
+ * feature-map rescale when pad > 0.  w2c_host may be NULL (points already in camera frame). */
+int zest_ndc_fwd(const float *pts, int M, const float *w2c_host, const float *k_host, float inv_w,
+                 float inv_h, float near, float far, int pad, int lindisp, float *out, void *stream);
+
 /* ---- MLP ---------------------------------------------------------------------------
  * Weights are re-packed once per parameter update into the order the MFMA engine
  * streams them.  zest_mlp_packed_bytes gives the buffer size; params is an array of

@@ -350,6 +350,44 @@ def rendering(rays_pts, rays_ndc, z, rays_dir, net_static, net_dynamic=None,
     return ret
 
 
+# ------------------------------------------------------------ ray sampling (8(f) next-1)
+def ndc_coordinate(pts, w2c, K, inv_w, inv_h, near, far, pad=0):
+    """pts [...,3] world -> (u, v, z) of a view, normalised and pad-rescaled.
+    Restates get_ndc_coordinate, /root/reference/utils.py:257-285 (projection branch)."""
+    p = pts.reshape(-1, 3)
+    pc = p @ w2c[:3, :3].t() + w2c[:3, 3]
+    q = pc @ K.t()
+    u = (q[:, 0] / q[:, 2] + 0.0) / inv_w
+    v = (q[:, 1] / q[:, 2] + 0.0) / inv_h
+    zn = (q[:, 2] - near) / (far - near)
+    if pad > 0:
+        wf, hf = (inv_w + 1) / 4.0, (inv_h + 1) / 4.0
+        v = v * hf / (hf + pad * 2) + pad / (hf + pad * 2)
+        u = u * wf / (wf + pad * 2) + pad / (wf + pad * 2)
+    return torch.stack([u, v, zn], -1).reshape(pts.shape)
+
+
+def sample_rays(xs, ys, K_tgt, c2w_tgt, w2c_ref, K_ref, near_tgt, far_tgt, near_ref, far_ref, S,
+                t_rand=None, pad=0, W=None, H=None):
+    """Pixels (xs, ys) [R] of the target camera -> rays_dir [R,3], depth [R,S], pts [R,S,3],
+    ndc [R,S,3].  Restates the per-sample part of build_rays_base and the direction part of
+    get_rays_mvs, /root/reference/utils.py:215-223, 361-387."""
+    dirs = torch.stack([(xs - K_tgt[0, 2]) / K_tgt[0, 0], (ys - K_tgt[1, 2]) / K_tgt[1, 1],
+                        torch.ones_like(xs)], -1)
+    d = dirs @ c2w_tgt[:3, :3].t()
+    o = c2w_tgt[:3, 3]
+    t = torch.linspace(0., 1., steps=S, dtype=xs.dtype)
+    z = (near_tgt * (1. - t) + far_tgt * t)[None].expand(xs.shape[0], S)
+    if t_rand is not None:
+        mids = .5 * (z[:, 1:] + z[:, :-1])
+        upper = torch.cat([mids, z[:, -1:]], -1)
+        lower = torch.cat([z[:, :1], mids], -1)
+        z = lower + (upper - lower) * t_rand
+    pts = o[None, None, :] + z[..., None] * d[:, None, :]
+    ndc = ndc_coordinate(pts, w2c_ref, K_ref, W - 1, H - 1, near_ref, far_ref, pad)
+    return d, z, pts, ndc
+
+
 def num_threads():
     return torch.get_num_threads()
 

@@ -124,6 +124,24 @@ def render_inputs(seed, R=32, S=16, V=3, use_mvs=True, scene_flow=False, use_mvs
     return sc
 
 
+def rays_inputs(seed, R=48, S=12, V=3, H=24, W=32):
+    """A batch dict as the generators hand it to build_rays[_dy]."""
+    g = zs.rng(seed)
+    w2cs, intr = zs.make_cameras(V + 1, H, W, focal=30.0)
+    c2ws = np.linalg.inv(w2cs[0].astype(np.float64)).astype(np.float32)[None]
+    nf = np.tile(np.array([2.0, 6.0], np.float32), (1, V + 1, 1))
+    nf[0, -1] = (2.25, 5.5)                       # target planes differ from the reference view's
+    return dict(imgs=g.uniform(0, 1, size=(1, V + 1, 3, H, W)).astype(np.float32),
+                depths=g.uniform(0.1, 1, size=(1, V + 1, H, W)).astype(np.float32), w2cs=w2cs, c2ws=c2ws,
+                intrinsics=intr, near_fars=nf, t_rand=g.uniform(0, 1, size=(R + 8, S)).astype(np.float32),
+                flow_fwd=g.standard_normal((1, 1, 2, H, W)).astype(np.float32),
+                flow_bwd=g.standard_normal((1, 1, 2, H, W)).astype(np.float32),
+                mask_fwd=(g.uniform(size=(1, 1, H, W)) > 0.5).astype(np.float32),
+                mask_bwd=(g.uniform(size=(1, 1, H, W)) > 0.5).astype(np.float32),
+                motion_coords=np.stack([g.integers(0, H, 20), g.integers(0, W, 20)], -1).astype(np.int64),
+                R=R, S=S, H=H, W=W)
+
+
 CASES = {
     "composite": dict(kind="composite", seed=11),
     "composite_white": dict(kind="composite", seed=12, white_bkgd=True),
@@ -134,6 +152,11 @@ CASES = {
     "volume": dict(kind="volume", seed=17),
     "color": dict(kind="color", seed=18),
     **{"mlp_" + k: dict(kind="mlp", seed=20 + i, variant=k) for i, k in enumerate(MLP_VARIANTS)},
+    "rays_random": dict(kind="rays", seed=51, pad=2, stratified=True, torch_seed=7),
+    "rays_grid_chunk": dict(kind="rays", seed=52, pad=0, stratified=False, isRandom=False, chunk=40, idx=3),
+    "rays_dy_motion": dict(kind="rays", seed=53, pad=2, stratified=True, torch_seed=11, scene_flow=True,
+                           num_extra_samples=8),
+    "rays_patches": dict(kind="rays", seed=54, pad=2, stratified=True, torch_seed=5, patch_size=4),
     "render_static_mvs": dict(kind="render", seed=31, use_mvs=True),
     "render_static_nomvs": dict(kind="render", seed=32, use_mvs=False),
     "render_static_white": dict(kind="render", seed=33, use_mvs=True, white_bkgd=True),
@@ -167,6 +190,8 @@ def build(case):
         return color_inputs(c["seed"])
     if k == "mlp":
         return mlp_inputs(c["seed"], c["variant"])
+    if k == "rays":
+        return rays_inputs(c["seed"])
     if k == "render":
         return render_inputs(c["seed"], use_mvs=c.get("use_mvs", True),
                              scene_flow=c.get("scene_flow", False),

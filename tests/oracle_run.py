@@ -57,6 +57,29 @@ def oracle_render(c, sc, dtype=torch.float32, explicit=True):
         noise=noise, explicit=explicit)
 
 
+def rays_pixels(c, inp):
+    """Pixel selection with the reference's RNG call order (utils.py:172-212) for the test cases."""
+    H, W, R = inp["H"], inp["W"], inp["R"]
+    torch.manual_seed(c.get("torch_seed", 0))
+    ps = c.get("patch_size", -1)
+    if ps > 0:
+        n = R // (ps * ps)
+        xb, yb = torch.randint(0, W - ps, (n,)), torch.randint(0, H - ps, (n,))
+        ar = torch.arange(ps, dtype=torch.float32)
+        ys = (yb.float()[:, None, None] + ar[None, :, None]).expand(-1, -1, ps).reshape(-1)
+        xs = (xb.float()[:, None, None] + ar[None, None, :]).expand(-1, ps, -1).reshape(-1)
+    elif c.get("isRandom", True):
+        xs, ys = torch.randint(0, W, (R,)).float(), torch.randint(0, H, (R,)).float()
+    else:
+        lin = torch.arange(c["idx"] * c["chunk"], min((c["idx"] + 1) * c["chunk"], H * W))
+        ys, xs = (lin // W).float(), (lin % W).float()
+    ne = c.get("num_extra_samples", 0)
+    if ne:
+        hard = torch.from_numpy(inp["motion_coords"])[torch.randint(0, inp["motion_coords"].shape[0], (ne,))]
+        xs, ys = torch.cat([xs, hard[:, 1].float()]), torch.cat([ys, hard[:, 0].float()])
+    return xs, ys
+
+
 def run(case, dtype=torch.float32, explicit=True):
     c = gc.CASES[case]
     inp = gc.build(case)
@@ -88,6 +111,25 @@ def run(case, dtype=torch.float32, explicit=True):
             spec = spec_of(inp["P"], inp["Fd"], inp["sceneflow"], inp["static"], inp["use_mvs"],
                            inp["net_type"])
             out["y"] = zo.mlp_forward(state_t(inp["state"], dtype), T(inp["x"], dtype)[0], spec)
+        elif k == "rays":
+            xs, ys = rays_pixels(c, inp)
+            t = lambda a: T(a, dtype)[0]
+            nf = inp["near_fars"][0]
+            tr = T(inp["t_rand"], dtype)[:xs.shape[0]] if c.get("stratified", True) else None
+            d, z, pts, ndc = zo.sample_rays(xs.to(dtype), ys.to(dtype), t(inp["intrinsics"])[-1], t(inp["c2ws"])[-1],
+                                            t(inp["w2cs"])[0], t(inp["intrinsics"])[0], float(nf[-1, 0]),
+                                            float(nf[-1, 1]), float(nf[0, 0]), float(nf[0, 1]), inp["S"], tr,
+                                            c.get("pad", 0), inp["W"], inp["H"])
+            yi, xi = ys.long(), xs.long()
+            out = dict(point_samples=pts[None], rays_d=d[None], points_ndc=ndc[None], depth_candidate=z[None],
+                       color=T(inp["imgs"], dtype)[:, -1, :, yi, xi].permute(0, 2, 1),
+                       rays_depth_gt=T(inp["depths"], dtype)[:, -1, yi, xi],
+                       t_vals=torch.linspace(0., 1., inp["S"], dtype=dtype)[None])
+            if c.get("scene_flow"):
+                out.update(rays_flow_fwd_gt=T(inp["flow_fwd"], dtype)[:, -1, :, yi, xi].permute(0, 2, 1),
+                           rays_flow_bwd_gt=T(inp["flow_bwd"], dtype)[:, -1, :, yi, xi].permute(0, 2, 1),
+                           rays_mask_fwd_gt=T(inp["mask_fwd"], dtype)[:, -1, yi, xi],
+                           rays_mask_bwd_gt=T(inp["mask_bwd"], dtype)[:, -1, yi, xi])
         elif k == "render":
             out = oracle_render(c, inp, dtype, explicit)
     return {kk: (v.double().numpy() if v is not None else None) for kk, v in out.items()}

@@ -168,6 +168,37 @@ def test_module_api(hip):
     close(w[0], cg["weights"], name="raw2alpha/weights")
 
 
+RAYS_CASES = [c for c in gc.CASES if gc.CASES[c]["kind"] == "rays"]
+
+
+@pytest.mark.parametrize("case", RAYS_CASES)
+def test_build_rays_matches_reference(hip, case):
+    """utils.build_rays_dy (ray sampling, the step in front of the renderer) against the
+    reference's outputs for the same seeded pixels and injected stratified jitter."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(gc.ROOT, "tools"))
+    import gen_golden
+    import utils
+    got = gen_golden.run_rays(utils, gc.CASES[case], gc.build(case), wrap=G)
+    gold = gc.load_golden(case)
+    assert sorted(got) == sorted(gold)
+    for k, v in gold.items():
+        close(got[k], v, atol=2e-6, rtol=2e-6, name="%s/%s" % (case, k))
+
+
+def test_get_ndc_coordinate(hip):
+    import utils
+    from oracle import zest_oracle as zo
+    inp = gc.build("rays_random")
+    pts = gc.zs.rng(9).uniform(-2, 2, size=(1, 5, 7, 3)).astype(np.float32) + np.array([0, 0, 4], np.float32)
+    w2c, K = G(inp["w2cs"])[:, 1], G(inp["intrinsics"])[:, 1]
+    got = utils.get_ndc_coordinate(w2c, K, G(pts), torch.tensor([31, 23]), near=2.0, far=6.0, pad=3)
+    want = zo.ndc_coordinate(torch.from_numpy(pts)[0], torch.from_numpy(inp["w2cs"])[0, 1],
+                             torch.from_numpy(inp["intrinsics"])[0, 1], 31, 23, 2.0, 6.0, 3)
+    close(got[0], want.numpy(), atol=2e-6, rtol=2e-6, name="get_ndc_coordinate")
+
+
 def test_ray_permutation_commutes(hip):
     """Rays are independent: rendering a permuted batch permutes the outputs (basis of the
     multi-GPU ray sharding)."""

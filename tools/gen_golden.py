@@ -109,9 +109,51 @@ def run_case(ref, name):
             net = ref_net(ref, inp["state"], inp["P"], inp["Fd"], inp["sceneflow"], inp["static"],
                           inp["use_mvs"], inp["net_type"])
             out["y"] = net(T(inp["x"])).numpy()[0]
+        elif k == "rays":
+            out = run_rays(ref.utils, c, inp)
         elif k == "render":
             out = run_render(ref, c, inp)
     return out
+
+
+RAYS_OUT = ("point_samples", "rays_d", "color", "points_ndc", "depth_candidate", "rays_depth_gt", "t_vals",
+            "rays_flow_fwd_gt", "rays_flow_bwd_gt", "rays_mask_fwd_gt", "rays_mask_bwd_gt")
+
+
+def run_rays(U, c, inp, wrap=T):
+    """Call build_rays_dy of module U (the reference, or the build's own utils in the tests) with
+    the stratified jitter injected and the pixel RNG seeded."""
+    sf = c.get("scene_flow", False)
+    real_rand = torch.rand
+    used = {}
+
+    def fake_rand(shape, *a, **kw):
+        n = wrap(inp["t_rand"][:shape[0]])
+        assert tuple(n.shape) == tuple(shape), (n.shape, shape)
+        used["n"] = shape[0]
+        return n
+    torch.manual_seed(c.get("torch_seed", 0))
+    hook = getattr(U, "_draw_uniform", None)
+    if hook is not None:
+        U._draw_uniform = lambda shape, device: fake_rand(shape)
+    else:
+        torch.rand = fake_rand
+    try:
+        r = U.build_rays_dy(wrap(inp["imgs"]), wrap(inp["depths"]), wrap(inp["w2cs"]), wrap(inp["c2ws"]),
+                            wrap(inp["intrinsics"]), wrap(inp["near_fars"]), inp["S"], N_rays=inp["R"],
+                            stratified=c.get("stratified", True), pad=c.get("pad", 0),
+                            chunk=c.get("chunk", -1), idx=c.get("idx", -1), val=not c.get("isRandom", True),
+                            isRandom=c.get("isRandom", True), patch_size=c.get("patch_size", -1),
+                            scene_flow=sf,
+                            flow_fwd=wrap(inp["flow_fwd"]) if sf else None, flow_bwd=wrap(inp["flow_bwd"]) if sf else None,
+                            mask_fwd=wrap(inp["mask_fwd"]) if sf else None, mask_bwd=wrap(inp["mask_bwd"]) if sf else None,
+                            num_extra_samples=c.get("num_extra_samples", 0),
+                            motion_coords=torch.from_numpy(inp["motion_coords"]) if c.get("num_extra_samples", 0) else None)
+    finally:
+        torch.rand = real_rand
+        if hook is not None:
+            U._draw_uniform = hook
+    return {n: v.detach().cpu().numpy() for n, v in zip(RAYS_OUT, r) if v is not None}
 
 
 def run_render(ref, c, sc):

@@ -1,0 +1,124 @@
+// Ray sampling: the step right before the renderer.
+// One thread per sample: depth candidate (uniform in [near, far], optionally jittered inside
+// its stratum), world point o + z d, and its coordinates in the reference view's padded
+// encoding volume.  Replaces the per-sample part of build_rays_base and get_ndc_coordinate
+// (reference utils.py:232-288, 361-387); pixel selection stays on the host (it is R integers
+// and defines the RNG call order).  HBM-bound: 4 B in (jitter), 28 B out per sample.
+#include "zest_sample_ops.cuh"
+
+namespace {
+
+struct RayCams {
+    float k_tgt[9], c2w_tgt[16];     // target view: intrinsics, camera-to-world
+    float w2c_ref[16], k_ref[9];     // reference view (volume frame)
+};
+
+// torch.linspace(0, 1, S)[i] in fp32: forward from the start for the first half, backward
+// from the end for the second (the library's symmetric evaluation)
+__device__ __forceinline__ float linspace01(int i, int S) {
+    if (S == 1) return 0.0f;
+    const float step = 1.0f / (float)(S - 1);
+    return i < S / 2 ? step * (float)i : 1.0f - step * (float)(S - 1 - i);
+}
+
+__device__ __forceinline__ void ndc_of(const float *w2c, const float *K, float px, float py, float pz,
+                                       float inv_w, float inv_h, float near, float far, int pad,
+                                       int lindisp, float out[3]) {
+    float cx = px, cy = py, cz = pz;
+    if (w2c) {
+        cx = fmaf(pz, w2c[2], fmaf(py, w2c[1], px * w2c[0])) + w2c[3];
+        cy = fmaf(pz, w2c[6], fmaf(py, w2c[5], px * w2c[4])) + w2c[7];
+        cz = fmaf(pz, w2c[10], fmaf(py, w2c[9], px * w2c[8])) + w2c[11];
+    }
+    const float qx = fmaf(cz, K[2], fmaf(cy, K[1], cx * K[0]));
+    const float qy = fmaf(cz, K[5], fmaf(cy, K[4], cx * K[3]));
+    const float qz = fmaf(cz, K[8], fmaf(cy, K[7], cx * K[6]));
+    float u = (qx / qz) / inv_w, v = (qy / qz) / inv_h;
+    const float zn = lindisp ? (1.0f / qz - 1.0f / near) / (1.0f / far - 1.0f / near)
+                             : (qz - near) / (far - near);
+    if (pad > 0) {
+        const float wf = (inv_w + 1.0f) / 4.0f, hf = (inv_h + 1.0f) / 4.0f;
+        u = u * wf / (wf + pad * 2) + pad / (wf + pad * 2);
+        v = v * hf / (hf + pad * 2) + pad / (hf + pad * 2);
+    }
+    out[0] = u, out[1] = v, out[2] = zn;
+}
+
+__global__ void build_rays_kernel(RayCams c, const float *__restrict__ xs, const float *__restrict__ ys,
+                                  const float *__restrict__ t_rand, int R, int S, float near_tgt,
+                                  float far_tgt, float near_ref, float far_ref, int pad, int W, int H,
+                                  float *__restrict__ rays_dir, float *__restrict__ depth,
+                                  float *__restrict__ pts, float *__restrict__ ndc) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= R * S) return;
+    const int r = m / S, s = m % S;
+    const float dx = (xs[r] - c.k_tgt[2]) / c.k_tgt[0], dy = (ys[r] - c.k_tgt[5]) / c.k_tgt[4];
+    float d[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) d[i] = dx * c.c2w_tgt[4 * i] + dy * c.c2w_tgt[4 * i + 1] + c.c2w_tgt[4 * i + 2];
+    if (s == 0) rays_dir[3 * r] = d[0], rays_dir[3 * r + 1] = d[1], rays_dir[3 * r + 2] = d[2];
+    auto zc = [&](int i) {
+        const float t = linspace01(i, S);
+        return near_tgt * (1.0f - t) + far_tgt * t;
+    };
+    float z = zc(s);
+    if (t_rand) {       // stratified: jitter inside [mid(s-1,s), mid(s,s+1)], clamped at the ends
+        const float lower = s > 0 ? 0.5f * (z + zc(s - 1)) : z;
+        const float upper = s + 1 < S ? 0.5f * (zc(s + 1) + z) : z;
+        z = lower + (upper - lower) * t_rand[m];
+    }
+    depth[m] = z;
+    const float px = c.c2w_tgt[3] + z * d[0], py = c.c2w_tgt[7] + z * d[1], pz = c.c2w_tgt[11] + z * d[2];
+    pts[3 * m] = px, pts[3 * m + 1] = py, pts[3 * m + 2] = pz;
+    float o[3];
+    ndc_of(c.w2c_ref, c.k_ref, px, py, pz, (float)(W - 1), (float)(H - 1), near_ref, far_ref, pad, 0, o);
+    ndc[3 * m] = o[0], ndc[3 * m + 1] = o[1], ndc[3 * m + 2] = o[2];
+}
+
+__global__ void ndc_kernel(RayCams c, int has_w2c, const float *__restrict__ pts, int M, float inv_w,
+                           float inv_h, float near, float far, int pad, int lindisp,
+                           float *__restrict__ out) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    float o[3];
+    ndc_of(has_w2c ? c.w2c_ref : nullptr, c.k_ref, pts[3 * m], pts[3 * m + 1], pts[3 * m + 2], inv_w, inv_h,
+           near, far, pad, lindisp, o);
+    out[3 * m] = o[0], out[3 * m + 1] = o[1], out[3 * m + 2] = o[2];
+}
+
+}  // namespace
+
+// Host matrices: the four small camera matrices are passed by value (host pointers), like
+// the reference which indexes them out of the batch dict on the host side.
+extern "C" int zest_build_rays_fwd(const float *xs, const float *ys, const float *t_rand, int R, int S,
+                                   const float *k_tgt_host, const float *c2w_tgt_host,
+                                   const float *w2c_ref_host, const float *k_ref_host, float near_tgt,
+                                   float far_tgt, float near_ref, float far_ref, int pad, int W, int H,
+                                   float *rays_dir, float *depth, float *pts, float *ndc, void *stream) {
+    ZEST_CHECK_ARG(xs && ys && k_tgt_host && c2w_tgt_host && w2c_ref_host && k_ref_host && rays_dir &&
+                       depth && pts && ndc, "zest_build_rays_fwd: null argument");
+    ZEST_CHECK_ARG(R >= 0 && S >= 1 && W >= 2 && H >= 2 && pad >= 0, "zest_build_rays_fwd: bad shape");
+    if (R == 0) return 0;
+    RayCams c;
+    for (int i = 0; i < 9; i++) c.k_tgt[i] = k_tgt_host[i], c.k_ref[i] = k_ref_host[i];
+    for (int i = 0; i < 16; i++) c.c2w_tgt[i] = c2w_tgt_host[i], c.w2c_ref[i] = w2c_ref_host[i];
+    hipLaunchKernelGGL(build_rays_kernel, dim3(zest_div_up((long long)R * S, 256)), dim3(256), 0,
+                       (hipStream_t)stream, c, xs, ys, t_rand, R, S, near_tgt, far_tgt, near_ref, far_ref,
+                       pad, W, H, rays_dir, depth, pts, ndc);
+    ZEST_RETURN_LAUNCH("zest_build_rays_fwd");
+}
+
+extern "C" int zest_ndc_fwd(const float *pts, int M, const float *w2c_host, const float *k_host,
+                            float inv_w, float inv_h, float near, float far, int pad, int lindisp,
+                            float *out, void *stream) {
+    ZEST_CHECK_ARG(pts && k_host && out, "zest_ndc_fwd: null argument");
+    ZEST_CHECK_ARG(M >= 0 && pad >= 0, "zest_ndc_fwd: bad shape");
+    if (M == 0) return 0;
+    RayCams c = {};
+    for (int i = 0; i < 9; i++) c.k_ref[i] = k_host[i];
+    if (w2c_host)
+        for (int i = 0; i < 16; i++) c.w2c_ref[i] = w2c_host[i];
+    hipLaunchKernelGGL(ndc_kernel, dim3(zest_div_up(M, 256)), dim3(256), 0, (hipStream_t)stream, c,
+                       w2c_host ? 1 : 0, pts, M, inv_w, inv_h, near, far, pad, lindisp, out);
+    ZEST_RETURN_LAUNCH("zest_ndc_fwd");
+}

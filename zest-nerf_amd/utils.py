@@ -13,7 +13,8 @@ import torch
 import zest_hip
 
 __all__ = ["index_point_feature", "build_color_volume", "volume_channels_last",
-           "images_channels_last"]
+           "images_channels_last", "get_ndc_coordinate", "get_rays_mvs", "build_rays_base",
+           "build_rays", "build_rays_dy"]
 
 _CL_CACHE = {}
 _CL_CACHE_MAX = 8
@@ -67,3 +68,124 @@ def build_color_volume(point_samples, poses, imgs, img_feat=None, downscale=1.0,
         return out
     V = icl.shape[0]
     return out.view(*out.shape[:-1], V, 4)[..., :3].reshape(*out.shape[:-1], 3 * V)
+
+
+# ---------------------------------------------------------------------------- ray sampling
+# The step in front of the renderer: same functions and return tuples
+# as the reference (utils.py:133-431).  Pixel selection is R integers and fixes the RNG call
+# order, so it stays on the host with the reference's own torch calls (a run seeded like the
+# reference picks the same pixels); everything per sample runs in zest_build_rays_fwd.
+def _draw_uniform(shape, device):
+    """Stratified jitter ~ U[0,1), one draw per call like the reference (utils.py:374).
+    Tests replace this hook to inject known numbers."""
+    return torch.rand(shape, device=device)
+
+
+def get_ndc_coordinate(w2c_ref, intrinsic_ref, point_samples, inv_scale, near=2, far=6, pad=0,
+                       lindisp=False):
+    """World points [N,R,S,3] -> [1,R,S,3] image-plane / depth coordinates of a view, normalised
+    by inv_scale and [near, far], with the padded-volume rescale (reference utils.py:232-288)."""
+    if intrinsic_ref is None:
+        raise NotImplementedError("get_ndc_coordinate: the bounding-box branch is unused by the "
+                                  "reference's callers and not implemented")
+    R, S = point_samples.shape[1], point_samples.shape[2]
+    inv = [float(v) for v in inv_scale.reshape(-1).tolist()]
+    out = zest_hip.ndc_coordinate(point_samples.reshape(-1, 3), None if w2c_ref is None else w2c_ref[0],
+                                  intrinsic_ref[0], inv[0], inv[1], float(near), float(far), pad, lindisp)
+    return out.view(1, R, S, 3)
+
+
+def get_rays_mvs(H, W, intrinsic, c2w, N_rays=1024, isRandom=True, chunk=-1, idx=-1, N_patches=None,
+                 patch_size=-1, scale_anneal=-1, step=0, variable_patches=False, num_extra_samples=0,
+                 motion_coords=None):
+    """Ray origin, un-normalised world directions and the (row, col) pixels they pass through
+    (reference utils.py:133-230).  -> rays_o [N,3], rays_d [N,R,3], pixel_coordinates [N,2,R]."""
+    device = c2w.device
+    if variable_patches:
+        raise NotImplementedError("get_rays_mvs: GRAF variable patches (adversarial SVS mode) are "
+                                  "outside the rendering path and not implemented")
+    if N_patches:
+        xb, yb = torch.randint(0, W - patch_size, (N_patches,)), torch.randint(0, H - patch_size, (N_patches,))
+        ar = torch.arange(patch_size, dtype=torch.float32)
+        ys = (yb.float()[:, None, None] + ar[None, :, None]).expand(-1, -1, patch_size).reshape(-1)
+        xs = (xb.float()[:, None, None] + ar[None, None, :]).expand(-1, patch_size, -1).reshape(-1)
+        if (ys < 0).any() or (ys >= H).any() or (xs < 0).any() or (xs >= W).any():
+            raise ValueError("point coordinates out of bounds")
+        ys, xs = ys.to(device), xs.to(device)
+    elif isRandom:
+        xs, ys = torch.randint(0, W, (N_rays,)).float().to(device), torch.randint(0, H, (N_rays,)).float().to(device)
+    else:
+        lo, hi = (idx * chunk, min((idx + 1) * chunk, H * W)) if chunk > 0 else (0, H * W)
+        lin = torch.arange(lo, hi, device=device)
+        ys, xs = (lin // W).float(), (lin % W).float()
+    xs, ys = xs[None].repeat(intrinsic.shape[0], 1), ys[None].repeat(intrinsic.shape[0], 1)
+    if motion_coords is not None and num_extra_samples > 0:
+        hard = motion_coords[torch.randint(0, motion_coords.shape[0], (num_extra_samples,))]
+        xs = torch.cat([xs, hard[:, 1].unsqueeze(0).to(xs)], dim=1)
+        ys = torch.cat([ys, hard[:, 0].unsqueeze(0).to(ys)], dim=1)
+    dirs = torch.stack([(xs - intrinsic[:, 0, 2].reshape(-1, 1)) / intrinsic[:, 0, 0].reshape(-1, 1),
+                        (ys - intrinsic[:, 1, 2].reshape(-1, 1)) / intrinsic[:, 1, 1].reshape(-1, 1),
+                        torch.ones_like(xs)], -1)
+    rays_d = torch.matmul(dirs, c2w[:, :3, :3].transpose(1, 2))
+    return c2w[:, :3, -1].clone(), rays_d, torch.stack((ys, xs), dim=1)
+
+
+def build_rays_base(imgs, depths, w2cs, c2ws, intrinsics, near_fars, N_samples, N_rays=1024,
+                    stratified=True, pad=0, chunk=-1, idx=-1, ref_idx=0, val=False, isRandom=True,
+                    patch_size=-1, scale_anneal=-1, step=0, variable_patches=False, scene_flow=False,
+                    flow_fwd=None, flow_bwd=None, mask_fwd=None, mask_bwd=None, num_extra_samples=0,
+                    motion_coords=None):
+    """Sample rays of the target (last) view and points along them; same 11-tuple as the
+    reference (utils.py:290-394)."""
+    device = imgs.device
+    N, V, C, H, W = imgs.shape
+    if N != 1:
+        raise RuntimeError("build_rays_base: image batch must be 1")
+    N_patches = None
+    if patch_size > 0:
+        N_patches = N_rays // (patch_size * patch_size)
+        assert N_rays % (patch_size * patch_size) == 0, \
+            "Batch size %d is not divisible by patch size of %d" % (N_rays, patch_size)
+    _, _, pix = get_rays_mvs(H, W, intrinsics[:, -1], c2ws[:, -1], N_rays, isRandom=isRandom, chunk=chunk,
+                             idx=idx, N_patches=N_patches, patch_size=patch_size, scale_anneal=scale_anneal,
+                             step=step, variable_patches=variable_patches,
+                             num_extra_samples=num_extra_samples, motion_coords=motion_coords)
+    ys, xs = pix[0, 0].contiguous(), pix[0, 1].contiguous()
+    R = xs.numel()
+    yi, xi = ys.long(), xs.long()
+    color = imgs[:, -1, :, yi, xi].permute(0, 2, 1)
+    rays_depth_gt = depths[:, -1, yi, xi]
+    gt = [None, None, None, None]
+    if scene_flow:
+        gt = [flow_fwd[:, -1, :, yi, xi].permute(0, 2, 1), flow_bwd[:, -1, :, yi, xi].permute(0, 2, 1),
+              mask_fwd[:, -1, yi, xi], mask_bwd[:, -1, yi, xi]]
+    t_rand = _draw_uniform((R, N_samples), device) if stratified else None
+    d, z, pts, ndc = zest_hip.build_rays(
+        xs, ys, t_rand, N_samples, intrinsics[0, -1], c2ws[0, -1], w2cs[0, ref_idx], intrinsics[0, ref_idx],
+        float(near_fars[0, -1, 0]), float(near_fars[0, -1, 1]), float(near_fars[0, ref_idx, 0]),
+        float(near_fars[0, ref_idx, 1]), pad, W, H)
+    t_vals = torch.linspace(0., 1., steps=N_samples).view(1, N_samples).to(device)
+    return (pts[None], d[None], color, ndc[None], z[None], rays_depth_gt, t_vals, gt[0], gt[1], gt[2], gt[3])
+
+
+def build_rays(imgs, depths, w2cs, c2ws, intrinsics, near_fars, N_samples, N_rays=1024, stratified=True,
+               pad=0, chunk=-1, idx=-1, ref_idx=0, val=False, isRandom=True, patch_size=-1,
+               scale_anneal=-1, step=0, variable_patches=False):
+    """Reference utils.py:396-407."""
+    return build_rays_base(imgs, depths, w2cs, c2ws, intrinsics, near_fars, N_samples, N_rays=N_rays,
+                           stratified=stratified, pad=pad, chunk=chunk, idx=idx, ref_idx=ref_idx, val=val,
+                           isRandom=isRandom, patch_size=patch_size, scale_anneal=scale_anneal, step=step,
+                           variable_patches=variable_patches, scene_flow=False)[:7]
+
+
+def build_rays_dy(imgs, depths, w2cs, c2ws, intrinsics, near_fars, N_samples, N_rays=1024, stratified=True,
+                  pad=0, chunk=-1, idx=-1, ref_idx=0, val=False, isRandom=True, patch_size=-1,
+                  scale_anneal=-1, step=0, variable_patches=False, scene_flow=False, flow_fwd=None,
+                  flow_bwd=None, mask_fwd=None, mask_bwd=None, num_extra_samples=0, motion_coords=None):
+    """Reference utils.py:409-431."""
+    return build_rays_base(imgs, depths, w2cs, c2ws, intrinsics, near_fars, N_samples, N_rays=N_rays,
+                           stratified=stratified, pad=pad, chunk=chunk, idx=idx, ref_idx=ref_idx, val=val,
+                           isRandom=isRandom, patch_size=patch_size, scale_anneal=scale_anneal, step=step,
+                           variable_patches=variable_patches, scene_flow=scene_flow, flow_fwd=flow_fwd,
+                           flow_bwd=flow_bwd, mask_fwd=mask_fwd, mask_bwd=mask_bwd,
+                           num_extra_samples=num_extra_samples, motion_coords=motion_coords)

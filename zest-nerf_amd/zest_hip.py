@@ -20,6 +20,7 @@ HEAD_NONE, HEAD_BLEND, HEAD_DYNAMIC = 0, 1, 2
 P_COUNT = 15
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_fp = C.POINTER(C.c_float)
 
 
 class MlpDesc(C.Structure):
@@ -56,6 +57,9 @@ _SIGS = {
     "zest_color_lookup_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "zest_encode_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp, _i, _i, _i, _vp, _i, _i, _i,
                              _vp, _vp, _vp, _vp]),
+    "zest_build_rays_fwd": (_i, [_vp, _vp, _vp, _i, _i, _fp, _fp, _fp, _fp, _f, _f, _f, _f, _i, _i, _i,
+                                 _vp, _vp, _vp, _vp, _vp]),
+    "zest_ndc_fwd": (_i, [_vp, _i, _fp, _fp, _f, _f, _f, _f, _i, _i, _vp, _vp]),
     "zest_mlp_packed_bytes": (_sz, [C.POINTER(MlpDesc), _i]),
     "zest_mlp_pack": (_i, [C.POINTER(MlpDesc), _i, C.POINTER(_vp), _vp, _vp]),
     "zest_mlp_fwd": (_i, [C.POINTER(MlpDesc), _i, _vp, _vp, _i, _vp, _vp]),
@@ -232,6 +236,40 @@ def encode(ndc, pts, rays_dir, t=None, vol_cl=None, imgs_cl=None, w2cs=None, int
                                  V, H, W, _ptr(w2cs), _ptr(intrinsics), _ptr(x), _stream(ndc)),
            "zest_encode_fwd")
     return x
+
+
+# ----------------------------------------------------------------------------- ray sampling
+def _host_mat(t, n):
+    """Small camera matrix -> ctypes float array (host)."""
+    v = t.detach().reshape(-1).float().cpu().tolist()
+    if len(v) != n:
+        raise RuntimeError("zest_hip: expected %d matrix entries, got %d" % (n, len(v)))
+    return (C.c_float * n)(*v)
+
+
+def build_rays(xs, ys, t_rand, S, k_tgt, c2w_tgt, w2c_ref, k_ref, near_tgt, far_tgt, near_ref, far_ref,
+               pad, W, H):
+    """xs, ys [R] pixel coordinates (device) -> rays_dir [R,3], depth [R,S], pts, ndc [R,S,3]."""
+    xs, ys, t_rand = _dev(xs, "xs"), _dev(ys, "ys"), _dev(t_rand, "t_rand")
+    R = xs.numel()
+    o = lambda *s: torch.empty(*s, device=xs.device, dtype=torch.float32)
+    d, z, pts, ndc = o(R, 3), o(R, S), o(R, S, 3), o(R, S, 3)
+    _check(lib().zest_build_rays_fwd(_ptr(xs), _ptr(ys), _ptr(t_rand), R, int(S), _host_mat(k_tgt, 9),
+                                     _host_mat(c2w_tgt, 16), _host_mat(w2c_ref, 16), _host_mat(k_ref, 9),
+                                     float(near_tgt), float(far_tgt), float(near_ref), float(far_ref),
+                                     int(pad), int(W), int(H), _ptr(d), _ptr(z), _ptr(pts), _ptr(ndc),
+                                     _stream(xs)), "zest_build_rays_fwd")
+    return d, z, pts, ndc
+
+
+def ndc_coordinate(pts, w2c, k, inv_w, inv_h, near, far, pad=0, lindisp=False):
+    pts = _dev(pts, "pts")
+    M = pts.numel() // 3
+    out = torch.empty_like(pts)
+    _check(lib().zest_ndc_fwd(_ptr(pts), M, _host_mat(w2c, 16) if w2c is not None else None,
+                              _host_mat(k, 9), float(inv_w), float(inv_h), float(near), float(far),
+                              int(pad), int(bool(lindisp)), _ptr(out), _stream(pts)), "zest_ndc_fwd")
+    return out
 
 
 # ----------------------------------------------------------------------------------- MLP

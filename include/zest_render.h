@@ -136,19 +136,68 @@ int zest_encode_fwd(const float *ndc, const float *pts, const float *rays_dir, i
  * near*(1-t)+far*t over t = linspace(0,1,S), jittered inside their strata when t_rand [R,S]
  * is given (the reference's torch.rand draw), points o + z d along the target camera's rays
  * through pixels (xs, ys) [R], and their coordinates in the reference view's padded volume
- * (get_ndc_coordinate, utils.py:232-288).  The four camera matrices are HOST pointers
- * (row-major 3x3 / 4x4).  Outputs: rays_dir [R,3], depth [R,S], pts [R,S,3], ndc [R,S,3]. */
+ * (get_ndc_coordinate, utils.py:232-288).  Camera matrices (row-major 3x3 / 4x4) and the
+ * (near, far) pairs are DEVICE pointers into the batch's camera tensors: no host round trip.
+ * Outputs: rays_dir [R,3], depth [R,S], pts [R,S,3], ndc [R,S,3]. */
 int zest_build_rays_fwd(const float *xs, const float *ys, const float *t_rand, int R, int S,
-                        const float *k_tgt_host, const float *c2w_tgt_host,
-                        const float *w2c_ref_host, const float *k_ref_host, float near_tgt,
-                        float far_tgt, float near_ref, float far_ref, int pad, int W, int H,
-                        float *rays_dir, float *depth, float *pts, float *ndc, void *stream);
+                        const float *k_tgt, const float *c2w_tgt, const float *w2c_ref,
+                        const float *k_ref, const float *near_far_tgt, const float *near_far_ref,
+                        int pad, int W, int H, float *rays_dir, float *depth, float *pts, float *ndc,
+                        void *stream);
 
 /* get_ndc_coordinate (reference utils.py:232-288): world pts [M,3] -> (u, v, z) normalised by
  * inv_scale = (inv_w, inv_h) and [near, far] (or inverse depth when lindisp), with the padded
- * feature-map rescale when pad > 0.  w2c_host may be NULL (points already in camera frame). */
-int zest_ndc_fwd(const float *pts, int M, const float *w2c_host, const float *k_host, float inv_w,
+ * feature-map rescale when pad > 0.  w2c [4,4] (device) may be NULL (points already in the
+ * camera frame); k [3,3] device. */
+int zest_ndc_fwd(const float *pts, int M, const float *w2c, const float *k, float inv_w,
                  float inv_h, float near, float far, int pad, int lindisp, float *out, void *stream);
+
+/* ---- compositing backward (training path) -----------------------------------------
+ * Gradient of zest_composite_fwd with respect to raw, given the gradients of the outputs
+ * the reference's losses consume: rgb_map [R,3], depth_map [R], acc_map [R], weights [R,S]
+ * (any may be NULL = zero).  disp_map and alpha have no consumer and carry no gradient.
+ * Same raw / z / rays_dir / noise as the forward call.  g_raw [R,S,4]. */
+int zest_composite_bwd(const float *raw, const float *z, const float *rays_dir, const float *noise,
+                       float noise_std, int white_bkgd, int R, int S, const float *g_rgb_map,
+                       const float *g_depth_map, const float *g_acc_map, const float *g_weights,
+                       float *g_raw, void *stream);
+
+/* Gradient of zest_composite_blend_fwd: given g of rgb_map, depth_map, rgb_map_fg,
+ * depth_map_fg, weights_fg, weights_dy (NULL = zero; weights_dd_sum is detached in the
+ * reference) -> g_raw_dy, g_raw_st [R,S,4], g_blend [R,S]. */
+int zest_composite_blend_bwd(const float *raw_dy, const float *raw_st, const float *blend,
+                             const float *z, const float *rays_dir, const float *noise,
+                             float noise_std, int R, int S, const float *g_rgb_map,
+                             const float *g_depth_map, const float *g_rgb_map_fg,
+                             const float *g_depth_map_fg, const float *g_weights_fg,
+                             const float *g_weights_dy, float *g_raw_dy, float *g_raw_st,
+                             float *g_blend, void *stream);
+
+/* Gradient of zest_encode_fwd for the inputs that carry gradients in the reference's training
+ * graph: g_x [R*S, C_in] -> g_ndc [R,S,3] (through the positional encoding and the trilinear
+ * lookup) and, if g_vol_cl is given, += the channels-last volume gradient [D,Hv,Wv,8]
+ * (atomic scatter-add; zero it first).  vol_cl / V as in the forward call (NULL / 0: no
+ * feature columns).  zest_volume_from_cl converts that gradient back to [8,D,H,W]. */
+int zest_encode_bwd(const float *g_x, const float *ndc, int R, int S, int has_time, float t,
+                    const float *vol_cl, int D, int Hv, int Wv, int V, float *g_ndc, float *g_vol_cl,
+                    void *stream);
+int zest_volume_from_cl(const float *vol_cl, int D, int H, int W, float *vol, void *stream);
+
+/* ---- MLP training path --------------------------------------------------------------
+ * fp32 forward that keeps what backward needs, and the backward: gradients with respect to
+ * the input x (point-encoding and feature columns; the direction columns are data) and to
+ * every parameter.  params / g_params: 2*ZEST_P_COUNT device pointers (weight, bias per
+ * ZEST_P_* slot, same layout as zest_mlp_pack; g_params entries are overwritten).
+ * saved / workspace: caller-owned scratch of zest_mlp_train_saved_floats /
+ * zest_mlp_train_workspace_floats floats; `saved` and `out` of the forward call must be handed
+ * unchanged to the backward call.  GEMMs run in rocBLAS sgemm (plain library shapes). */
+size_t zest_mlp_train_saved_floats(const zest_mlp_desc *desc, int M);
+size_t zest_mlp_train_workspace_floats(const zest_mlp_desc *desc, int M);
+int zest_mlp_train_fwd(const zest_mlp_desc *desc, const float *const *params, const float *x, int M,
+                       float *saved, float *workspace, float *out, void *stream);
+int zest_mlp_train_bwd(const zest_mlp_desc *desc, const float *const *params, const float *x, int M,
+                       const float *saved, const float *out, const float *g_out, float *workspace,
+                       float *g_x, float *const *g_params, void *stream);
 
 /* ---- MLP ---------------------------------------------------------------------------
  * Weights are re-packed once per parameter update into the order the MFMA engine

@@ -318,7 +318,7 @@ def rendering(rays_pts, rays_ndc, z, rays_dir, net_static, net_dynamic=None,
         raw_ref[..., :4], raw_rgba, blend, z, dists,
         noise["blend"] * raw_noise_std if use_noise else None)
     ret.update(rgb_map_ref=rgb_ref, depth_map_ref=depth_ref, rgb_map_ref_dy=rgb_fg,
-               depth_map_ref_dy=depth_fg, weights_map_dd=w_dd.sum(-1))
+               depth_map_ref_dy=depth_fg, weights_map_dd=w_dd.sum(-1).detach())   # renderer.py:436
     if val:
         return ret
     ret.update(raw_sf_ref2prev=sf_prev, raw_sf_ref2post=sf_post, raw_pts_ref=p_ref[..., :3],
@@ -336,8 +336,9 @@ def rendering(rays_pts, rays_ndc, z, rays_dir, net_static, net_dynamic=None,
     ret.update(raw_pts_prev=p_prev[..., :3], raw_sf_prev2ref=raw_prev[..., 7:10],
                rgb_map_prev_dy=rgb_prev, raw_pts_post=p_post[..., :3],
                raw_sf_post2ref=raw_post[..., 4:7], rgb_map_post_dy=rgb_post,
-               prob_map_prev=(w_prev * (1.0 - prob_prev)).sum(-1),
-               prob_map_post=(w_post * (1.0 - prob_post)).sum(-1))
+               # compute_2d_prob detaches the weights (renderer.py:31)
+               prob_map_prev=(w_prev.detach() * (1.0 - prob_prev)).sum(-1),
+               prob_map_post=(w_post.detach() * (1.0 - prob_post)).sum(-1))
     step2 = 2.0 / num_frames * 2.0
     if chain_bwd:
         ndc_pp, t_pp = p_prev[..., :3] + raw_prev[..., 4:7], ref_frame_idx - step2

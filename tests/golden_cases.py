@@ -170,9 +170,31 @@ CASES = {
                               raw_noise_std=1.0),
     "render_zest_nomvsdy": dict(kind="render", seed=40, scene_flow=True, val=True,
                                 use_mvs_dy=False),
+    "grad_zest_5f": dict(kind="render_grad", seed=41, scene_flow=True, chain_5frames=True),
+    "grad_static": dict(kind="render_grad", seed=42, use_mvs=True, white_bkgd=True),
 }
 
 REF_FRAME_IDX, NUM_FRAMES = 0.1, 24
+
+# outputs of a train-mode rendering() call that carry gradients; the gradient tests use
+# loss = sum_k <W_k, out_k> with W_k ~ N(0,1) drawn in this order from rng(seed + 777)
+LOSS_KEYS = ["rgb_map", "depth_map", "weights", "raw_blend_w", "rgb_map_ref", "depth_map_ref", "rgb_map_ref_dy",
+             "depth_map_ref_dy", "raw_sf_ref2prev", "raw_sf_ref2post", "weights_ref_dy", "raw_prob_ref2prev",
+             "raw_prob_ref2post", "raw_pts_prev", "raw_sf_prev2ref", "rgb_map_prev_dy", "raw_pts_post",
+             "raw_sf_post2ref", "rgb_map_post_dy", "prob_map_prev", "prob_map_post", "raw_pts_pp", "rgb_map_pp_dy"]
+
+
+def loss_weights(seed, shapes):
+    """{key: ndarray} of fixed loss weights for the keys of `shapes` (dict key -> shape, no batch dim)."""
+    g = zs.rng(seed + 777)
+    return {k: g.standard_normal(shapes[k]).astype(np.float32) for k in LOSS_KEYS if k in shapes}
+
+
+def grad_digest(t):
+    """Compact fingerprint of a gradient tensor: (sum, L2 norm, dot with a fixed N(0,1) vector)."""
+    a = np.asarray(t, np.float64).reshape(-1)
+    r = zs.rng(a.size).standard_normal(a.size)
+    return np.array([a.sum(), np.sqrt((a * a).sum()), (a * r).sum()])
 
 
 def build(case):
@@ -192,7 +214,7 @@ def build(case):
         return mlp_inputs(c["seed"], c["variant"])
     if k == "rays":
         return rays_inputs(c["seed"])
-    if k == "render":
+    if k in ("render", "render_grad"):
         return render_inputs(c["seed"], use_mvs=c.get("use_mvs", True),
                              scene_flow=c.get("scene_flow", False),
                              use_mvs_dy=c.get("use_mvs_dy", True))

@@ -133,3 +133,40 @@ def run(case, dtype=torch.float32, explicit=True):
         elif k == "render":
             out = oracle_render(c, inp, dtype, explicit)
     return {kk: (v.double().numpy() if v is not None else None) for kk, v in out.items()}
+
+
+def oracle_render_grads(case, dtype=torch.float32):
+    """Train-mode oracle call with autograd.  -> (ret dict of tensors, {leaf name: grad ndarray})
+    with the leaf naming of tools/gen_golden.py (static.nerf.<param>, dynamic.nerf.<param>,
+    vol_static, vol_dynamic) and the loss of golden_cases.loss_weights."""
+    c, sc = gc.CASES[case], gc.build(case)
+    sf = sc["scene_flow"]
+    ns, nd = render_nets(sc, dtype)
+    leaves = {}
+    for tag, net in (("static", ns), ("dynamic", nd)):
+        if net is None:
+            continue
+        for k in list(net.state):
+            if tag == "static" and not sc["use_mvs"] and "pts_bias" in k:
+                continue
+            net.state[k] = net.state[k].clone().requires_grad_(True)
+            leaves["%s.%s" % (tag, k)] = net.state[k]
+    t = lambda k: T(sc[k], dtype)[0]
+    vol_s = t("vol_static").requires_grad_(True) if sc["use_mvs"] else None
+    vol_d = t("vol_dynamic").requires_grad_(True) if (sf and sc["use_mvs_dy"]) else None
+    if vol_s is not None:
+        leaves["vol_static"] = vol_s
+    if vol_d is not None:
+        leaves["vol_dynamic"] = vol_d
+    cams = (t("w2cs"), t("intrinsics"))
+    nb_cams = (t("nb_w2cs"), t("nb_intrinsics")) if (sf and sc["use_mvs_dy"]) else None
+    ret = zo.rendering(t("rays_pts"), t("rays_ndc"), t("depth_candidates"), t("rays_dir"), ns, nd,
+                       vol_static=vol_s, vol_dynamic=vol_d, imgs=t("imgs") if sc["use_mvs"] else None,
+                       nb_imgs=t("nb_imgs") if (sf and sc["use_mvs_dy"]) else None, cams=cams, nb_cams=nb_cams,
+                       scene_flow=sf, val=False, chain_bwd=c.get("chain_bwd", False),
+                       chain_5frames=c.get("chain_5frames", False), ref_frame_idx=gc.REF_FRAME_IDX,
+                       num_frames=gc.NUM_FRAMES, white_bkgd=c.get("white_bkgd", False), explicit=False)
+    W = gc.loss_weights(c["seed"], {k: tuple(v.shape) for k, v in ret.items() if v is not None})
+    loss = sum((T(W[k], dtype) * ret[k]).sum() for k in W)
+    loss.backward()
+    return float(loss.detach()), {k: v.grad.double().numpy() for k, v in leaves.items()}

@@ -18,7 +18,7 @@ ATOL, RTOL = 2e-6, 2e-5
 ATOL_CHAIN, RTOL_CHAIN = 1e-4, 1e-3
 
 
-@pytest.mark.parametrize("case", list(gc.CASES))
+@pytest.mark.parametrize("case", [c for c in gc.CASES if gc.CASES[c]["kind"] != "render_grad"])
 @pytest.mark.parametrize("explicit", [True, False])
 def test_oracle_matches_reference(case, explicit):
     if gc.CASES[case]["kind"] not in ("volume", "color", "render") and not explicit:

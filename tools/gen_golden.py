@@ -78,7 +78,7 @@ def run_case(ref, name):
     inp = gc.build(name)
     k = c["kind"]
     out = {}
-    with torch.no_grad():
+    with torch.set_grad_enabled(k == "render_grad"):
         if k == "composite":
             z, d = T(inp["z"])[None], T(inp["rays_dir"])[None]
             dists = ref.renderer.depth2dist(z, torch.norm(d, dim=-1, keepdim=True))
@@ -113,7 +113,22 @@ def run_case(ref, name):
             out = run_rays(ref.utils, c, inp)
         elif k == "render":
             out = run_render(ref, c, inp)
+    if k == "render_grad":
+        out = run_render_grad(ref, c, inp)
     return out
+
+
+def run_render_grad(ref, c, sc):
+    """Reference training-mode call with autograd: digests of dLoss/d(parameter | volume)."""
+    grads = {}
+    ret, leaves = run_render(ref, c, sc, want_grad=True)
+    W = gc.loss_weights(c["seed"], {k: tuple(v.shape[1:]) for k, v in ret.items() if v is not None})
+    loss = sum((T(W[k]) * ret[k][0]).sum() for k in W)
+    loss.backward()
+    for name, t in leaves.items():
+        grads[name] = gc.grad_digest(t.grad.numpy())
+    grads["__loss__"] = np.array([float(loss)])
+    return grads
 
 
 RAYS_OUT = ("point_samples", "rays_d", "color", "points_ndc", "depth_candidate", "rays_depth_gt", "t_vals",
@@ -156,7 +171,7 @@ def run_rays(U, c, inp, wrap=T):
     return {n: v.detach().cpu().numpy() for n, v in zip(RAYS_OUT, r) if v is not None}
 
 
-def run_render(ref, c, sc):
+def run_render(ref, c, sc, want_grad=False):
     sf = c.get("scene_flow", False)
     args = SimpleNamespace(netchunk=1024, feat_dim=sc["feat_dim"], feat_dim_dy=sc["feat_dim_dy"],
                            img_downscale=1.0, use_color_volume=False, net_type="v0")
@@ -167,6 +182,22 @@ def run_render(ref, c, sc):
     net_d = None
     if sf:
         net_d = ref_net(ref, sc["state_dynamic"], gc.PE_XYZT, 24, True, False, sc["use_mvs_dy"])
+    leaves = {}
+    if want_grad:
+        for tag, net in (("static", net_s), ("dynamic", net_d)):
+            if net is not None:
+                net.train()
+                for n_, p_ in net.named_parameters():
+                    if tag == "static" and not sc["use_mvs"] and "pts_bias" in n_:
+                        continue
+                    leaves["%s.%s" % (tag, n_)] = p_
+    vol_s = T(sc["vol_static"]).requires_grad_(want_grad) if sc["use_mvs"] else None
+    vol_d = T(sc["vol_dynamic"]).requires_grad_(want_grad) if (sf and sc["use_mvs_dy"]) else None
+    if want_grad:
+        if vol_s is not None:
+            leaves["vol_static"] = vol_s
+        if vol_d is not None:
+            leaves["vol_dynamic"] = vol_d
     cam = {"w2cs": T(sc["w2cs"]), "intrinsics": T(sc["intrinsics"])}
     nb_cam = None
     if sf and sc["use_mvs_dy"]:
@@ -183,8 +214,7 @@ def run_render(ref, c, sc):
     try:
         ret = ref.renderer.rendering(
             args, T(sc["rays_pts"]), T(sc["rays_ndc"]), T(sc["depth_candidates"]), T(sc["rays_dir"]),
-            volume_feature_static=T(sc["vol_static"]) if sc["use_mvs"] else None,
-            volume_feature_dynamic=T(sc["vol_dynamic"]) if (sf and sc["use_mvs_dy"]) else None,
+            volume_feature_static=vol_s, volume_feature_dynamic=vol_d,
             imgs=T(sc["imgs"]) if sc["use_mvs"] else None,
             neighbour_frames=T(sc["nb_imgs"]) if (sf and sc["use_mvs_dy"]) else None,
             im_cam_mat=cam, nb_cam_mat=nb_cam, network_fn=net_s, network_fn_dy=net_d,
@@ -195,6 +225,8 @@ def run_render(ref, c, sc):
             raw_noise_std=std)
     finally:
         torch.randn = real_randn
+    if want_grad:
+        return ret, leaves
     out = {}
     for kk, v in ret.items():
         if v is not None:

@@ -128,9 +128,107 @@ __global__ void encode_kernel(const float *__restrict__ ndc, const float *__rest
     }
 }
 
+// Backward of encode_kernel for the inputs that carry gradients in the reference's training
+// graph: the volume coordinates (through the positional encoding and through the trilinear
+// lookup's dependence on them - needed for the scene-flow displaced points, renderer.py:461,488)
+// and the encoding volume itself (scatter-add; MVSNet trains through it).  World points, source
+// images, cameras and ray directions are data and receive no gradient.
+__global__ void encode_bwd_kernel(const float *__restrict__ g_x, const float *__restrict__ ndc, int R, int S,
+                                  int has_time, float t, const float4 *__restrict__ vol, int D, int Hv, int Wv,
+                                  int V, float *__restrict__ g_ndc, float *__restrict__ g_vol) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= R * S) return;
+    const int C = 3 + has_time;
+    const int P = C * 21, F = vol ? 8 + 4 * V : 0;
+    const float *row = g_x + (size_t)m * (P + F + 27);
+    const float p[3] = {ndc[3 * m], ndc[3 * m + 1], ndc[3 * m + 2]};
+    float g[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float acc = row[c], f = 1.0f;
+        for (int k = 0; k < 10; k++) {
+            float sn, cs;
+            zest_sincos(p[c] * f, &sn, &cs);
+            acc += f * (cs * row[C * (1 + 2 * k) + c] - sn * row[C * (2 + 2 * k) + c]);
+            f *= 2.0f;
+        }
+        g[c] = acc;
+    }
+    if (vol) {
+        float gf[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) gf[i] = row[P + i];
+        float fx = zest_unnorm(p[0], Wv), fy = zest_unnorm(p[1], Hv), fz = zest_unnorm(p[2], D);
+        const bool inside = fx > -2.0f && fx < (float)Wv + 1.0f && fy > -2.0f && fy < (float)Hv + 1.0f &&
+                            fz > -2.0f && fz < (float)D + 1.0f;
+        if (inside) {
+            const float x0f = floorf(fx), y0f = floorf(fy), z0f = floorf(fz);
+            const float tx = fx - x0f, ty = fy - y0f, tz = fz - z0f;
+            const int x0 = (int)x0f, y0 = (int)y0f, z0 = (int)z0f;
+            float dxs = 0.f, dys = 0.f, dzs = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
+                const int xi = x0 + dx, yi = y0 + dy, zi = z0 + dz;
+                if ((unsigned)xi < (unsigned)Wv && (unsigned)yi < (unsigned)Hv && (unsigned)zi < (unsigned)D) {
+                    const size_t vox = ((size_t)zi * Hv + yi) * Wv + xi;
+                    const float wx = dx ? tx : 1.0f - tx, wy = dy ? ty : 1.0f - ty, wz = dz ? tz : 1.0f - tz;
+                    const float4 a = vol[2 * vox], b = vol[2 * vox + 1];
+                    const float dot = a.x * gf[0] + a.y * gf[1] + a.z * gf[2] + a.w * gf[3] + b.x * gf[4] +
+                                      b.y * gf[5] + b.z * gf[6] + b.w * gf[7];
+                    dxs += (dx ? 1.0f : -1.0f) * wy * wz * dot;
+                    dys += (dy ? 1.0f : -1.0f) * wx * wz * dot;
+                    dzs += (dz ? 1.0f : -1.0f) * wx * wy * dot;
+                    if (g_vol) {
+                        const float w = wx * wy * wz;
+                        float *gv = g_vol + 8 * vox;
+#pragma unroll
+                        for (int i = 0; i < 8; i++) atomicAdd(gv + i, w * gf[i]);
+                    }
+                }
+            }
+            g[0] += dxs * (float)(Wv - 1), g[1] += dys * (float)(Hv - 1), g[2] += dzs * (float)(D - 1);
+        }
+    }
+    g_ndc[3 * m] = g[0], g_ndc[3 * m + 1] = g[1], g_ndc[3 * m + 2] = g[2];
+}
+
+// channels-last gradient volume [D,H,W,8] -> the reference's layout [8,D,H,W]
+__global__ void volume_from_cl_kernel(const float4 *__restrict__ cl, long long nvox, float *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nvox) return;
+    const float4 a = cl[2 * i], b = cl[2 * i + 1];
+    out[i] = a.x, out[nvox + i] = a.y, out[2 * nvox + i] = a.z, out[3 * nvox + i] = a.w;
+    out[4 * nvox + i] = b.x, out[5 * nvox + i] = b.y, out[6 * nvox + i] = b.z, out[7 * nvox + i] = b.w;
+}
+
 inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
+
+extern "C" int zest_encode_bwd(const float *g_x, const float *ndc, int R, int S, int has_time, float t,
+                               const float *vol_cl, int D, int Hv, int Wv, int V, float *g_ndc,
+                               float *g_vol_cl, void *stream) {
+    ZEST_CHECK_ARG(g_x && ndc && g_ndc, "zest_encode_bwd: g_x, ndc and g_ndc are required");
+    ZEST_CHECK_ARG(R >= 0 && S >= 1, "zest_encode_bwd: bad shape");
+    ZEST_CHECK_ARG(!vol_cl || (aligned16(vol_cl) && D >= 1 && Hv >= 1 && Wv >= 1 && V >= 1),
+                   "zest_encode_bwd: bad volume");
+    ZEST_CHECK_ARG(!g_vol_cl || vol_cl, "zest_encode_bwd: g_vol_cl needs vol_cl");
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(encode_bwd_kernel, dim3(zest_div_up((long long)R * S, kThreads)), dim3(kThreads), 0,
+                       (hipStream_t)stream, g_x, ndc, R, S, has_time ? 1 : 0, t, (const float4 *)vol_cl, D, Hv,
+                       Wv, V, g_ndc, g_vol_cl);
+    ZEST_RETURN_LAUNCH("zest_encode_bwd");
+}
+
+extern "C" int zest_volume_from_cl(const float *vol_cl, int D, int H, int W, float *vol, void *stream) {
+    ZEST_CHECK_ARG(vol_cl && vol && aligned16(vol_cl), "zest_volume_from_cl: bad pointer");
+    ZEST_CHECK_ARG(D >= 1 && H >= 1 && W >= 1, "zest_volume_from_cl: bad shape");
+    const long long n = (long long)D * H * W;
+    hipLaunchKernelGGL(volume_from_cl_kernel, dim3(zest_div_up(n, kThreads)), dim3(kThreads), 0,
+                       (hipStream_t)stream, (const float4 *)vol_cl, n, vol);
+    ZEST_RETURN_LAUNCH("zest_volume_from_cl");
+}
 
 extern "C" int zest_embed_fwd(const float *x, int M, int C, int L, float *y, void *stream) {
     ZEST_CHECK_ARG(x && y, "zest_embed_fwd: null pointer");

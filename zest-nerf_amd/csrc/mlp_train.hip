@@ -1,0 +1,340 @@
+// Training path of the width-256 MLP: fp32 forward that keeps the
+// activations backward needs, and the backward itself.  The GEMMs here are plain library
+// shapes ([M x K] . [K x 256] with M = rays x samples), so they go to rocBLAS sgemm (exact
+// fp32 products on gfx950: there is no xf32 path); everything between them - bias,
+// multiplicative / additive modulation by pts_bias(feats), ReLU and its mask, the skip
+// concatenation, head activations - is fused into three small HIP kernels.
+//
+// Layout of one sample's saved activations (kSavedPerSample floats), row-major per buffer:
+//   pre[l] = Linear_l(h) + b_l  for the 8 trunk layers, m = pts_bias(feats), the
+//   feature_linear output, and the pre-activation of the view layer.
+// Replaces the autograd of Renderer.forward / Renderer_linear.forward
+// (reference networks.py:150-221, 283-319).
+#include <rocblas/rocblas.h>
+#include <mutex>
+#include "zest_common.cuh"
+
+namespace {
+
+constexpr int W = 256, HW = 128;
+constexpr int kSavedPerSample = 8 * W + W + W + HW;                 // 2688
+constexpr int kWorkPerSample = 2 * W /*act ping-pong*/ + 4 * W /*d_a, d_b, act_re, dm*/ + W /*d_feat*/ +
+                               HW /*d_hv*/ + 16 /*head pre / d*/ + 1 /*ones*/;
+
+struct Shape {
+    int P, F, V, C_in, C_out, head, v2, mod, n_extra;
+};
+
+Shape shape_of(const zest_mlp_desc &d) {
+    Shape s;
+    s.P = d.in_ch_pts, s.mod = d.use_feat ? 1 : 0, s.F = s.mod ? d.in_ch_feat : 0, s.V = d.in_ch_views;
+    s.C_in = s.P + s.F + s.V, s.head = d.head, s.v2 = d.net_type == 2;
+    s.n_extra = d.head == ZEST_HEAD_BLEND ? 1 : (d.head == ZEST_HEAD_DYNAMIC ? 8 : 0);
+    s.C_out = 4 + s.n_extra;
+    return s;
+}
+
+rocblas_handle g_handle = nullptr;
+std::mutex g_mu;
+
+rocblas_handle handle_for(hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_handle && rocblas_create_handle(&g_handle) != rocblas_status_success) return nullptr;
+    rocblas_set_stream(g_handle, st);
+    rocblas_set_pointer_mode(g_handle, rocblas_pointer_mode_host);
+    return g_handle;
+}
+
+// Row-major helpers on top of column-major sgemm.
+// Y[M,N] (ldy) = X[M,K] (ldx) . Wt[N,K]^T (ldw)  (+ beta Y)
+bool gemm_xwT(rocblas_handle h, int M, int N, int K, const float *X, int ldx, const float *Wt, int ldw,
+              float *Y, int ldy, float beta) {
+    const float one = 1.0f;
+    return rocblas_sgemm(h, rocblas_operation_transpose, rocblas_operation_none, N, M, K, &one, Wt, ldw, X, ldx,
+                         &beta, Y, ldy) == rocblas_status_success;
+}
+// dX[M,K] (ldx) = dY[M,N] (ldy) . Wt[N,K] (ldw)  (+ beta dX)
+bool gemm_dx(rocblas_handle h, int M, int N, int K, const float *dY, int ldy, const float *Wt, int ldw,
+             float *dX, int ldx, float beta) {
+    const float one = 1.0f;
+    return rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_none, K, M, N, &one, Wt, ldw, dY, ldy,
+                         &beta, dX, ldx) == rocblas_status_success;
+}
+// dWt[N,K] (ldw) = dY[M,N]^T (ldy) . X[M,K] (ldx)
+bool gemm_dw(rocblas_handle h, int M, int N, int K, const float *dY, int ldy, const float *X, int ldx,
+             float *dWt, int ldw) {
+    const float one = 1.0f, zero = 0.0f;
+    return rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_transpose, K, N, M, &one, X, ldx, dY, ldy,
+                         &zero, dWt, ldw) == rocblas_status_success;
+}
+// db[N] = column sums of dY[M,N] (ldy)
+bool col_sums(rocblas_handle h, int M, int N, const float *dY, int ldy, const float *ones, float *db) {
+    const float one = 1.0f, zero = 0.0f;
+    return rocblas_sgemv(h, rocblas_operation_none, N, M, &one, dY, ldy, ones, 1, &zero, db, 1) ==
+           rocblas_status_success;
+}
+
+// pre = y + b (in place);  act = relu(mod(pre, m))          [n columns per row]
+__global__ void bias_act_kernel(float *__restrict__ pre, const float *__restrict__ b,
+                                const float *__restrict__ m, float *__restrict__ act, long long n_elem,
+                                int n, int v2, int relu) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_elem) return;
+    const float p = pre[i] + b[i % n];
+    pre[i] = p;
+    if (act) {
+        float v = m ? (v2 ? p + m[i] : p * m[i]) : p;
+        act[i] = relu ? fmaxf(v, 0.f) : v;
+    }
+}
+// act = relu(mod(pre, m)) from saved pre (backward recompute)
+__global__ void react_kernel(const float *__restrict__ pre, const float *__restrict__ m,
+                             float *__restrict__ act, long long n_elem, int v2) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_elem) return;
+    const float p = pre[i];
+    act[i] = fmaxf(m ? (v2 ? p + m[i] : p * m[i]) : p, 0.f);
+}
+// d (in: dL/dact, out: dL/dpre) and dm += dL/dm, through relu(mod(pre, m))
+__global__ void act_bwd_kernel(float *__restrict__ d, const float *__restrict__ pre,
+                               const float *__restrict__ m, float *__restrict__ dm, long long n_elem, int v2) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_elem) return;
+    const float p = pre[i], g = d[i];
+    if (!m) {
+        d[i] = p > 0.f ? g : 0.f;
+        return;
+    }
+    const float mv = m[i];
+    const bool on = (v2 ? p + mv : p * mv) > 0.f;
+    const float go = on ? g : 0.f;
+    d[i] = v2 ? go : go * mv;
+    dm[i] += v2 ? go : go * p;
+}
+__global__ void fill_kernel(float *__restrict__ p, long long n, float v) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+// head pre-activations hp[M,16] (0-2 rgb, 3 alpha, 4.. extras) -> out[M,C_out] with the
+// network's output activations (v0: raw rgb/alpha; v2: sigmoid rgb, relu alpha;
+// sigmoid blend / tanh scene flow / sigmoid prob)
+__global__ void heads_fwd_kernel(const float *__restrict__ hp, int M, int C_out, int head, int v2,
+                                 float *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)M * C_out) return;
+    const int c = (int)(i % C_out);
+    const float v = hp[(i / C_out) * 16 + c];
+    float o = v;
+    if (c < 3) o = v2 ? zest_sigmoid(v) : v;
+    else if (c == 3) o = v2 ? fmaxf(v, 0.f) : v;
+    else if (head == ZEST_HEAD_DYNAMIC && c <= 9) o = tanhf(v);
+    else o = zest_sigmoid(v);
+    out[i] = o;
+}
+// dL/dout -> dL/d(head pre-activation) using the saved outputs
+__global__ void heads_bwd_kernel(const float *__restrict__ g_out, const float *__restrict__ out, int M,
+                                 int C_out, int head, int v2, float *__restrict__ dhp) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)M * 16) return;
+    const int c = (int)(i % 16);
+    const long long m = i / 16;
+    float d = 0.f;
+    if (c < C_out) {
+        const float g = g_out[m * C_out + c], o = out[m * C_out + c];
+        if (c < 3) d = v2 ? g * o * (1.f - o) : g;
+        else if (c == 3) d = v2 ? (o > 0.f ? g : 0.f) : g;
+        else if (head == ZEST_HEAD_DYNAMIC && c <= 9) d = g * (1.f - o * o);
+        else d = g * o * (1.f - o);
+    }
+    dhp[i] = d;
+}
+
+inline dim3 grid1(long long n) { return dim3((unsigned)((n + 255) / 256)); }
+
+struct Params {                 // weight / bias pointers by ZEST_P_* slot
+    const float *w[ZEST_P_COUNT], *b[ZEST_P_COUNT];
+};
+struct GradParams {
+    float *w[ZEST_P_COUNT], *b[ZEST_P_COUNT];
+};
+
+}  // namespace
+
+extern "C" size_t zest_mlp_train_saved_floats(const zest_mlp_desc *desc, int M) {
+    return desc && M > 0 ? (size_t)M * kSavedPerSample : 0;
+}
+extern "C" size_t zest_mlp_train_workspace_floats(const zest_mlp_desc *desc, int M) {
+    return desc && M > 0 ? (size_t)M * kWorkPerSample : 0;
+}
+
+#define RB(x)                                                       \
+    do {                                                            \
+        if (!(x)) {                                                 \
+            zest_set_error("zest_mlp_train: rocBLAS call failed");  \
+            return (int)hipErrorUnknown;                            \
+        }                                                           \
+    } while (0)
+#define EW(kernel, n, ...) hipLaunchKernelGGL(kernel, grid1(n), dim3(256), 0, st, __VA_ARGS__)
+
+extern "C" int zest_mlp_train_fwd(const zest_mlp_desc *desc, const float *const *params, const float *x,
+                                  int M, float *saved, float *workspace, float *out, void *stream) {
+    ZEST_CHECK_ARG(desc && params && x && saved && workspace && out && M > 0, "zest_mlp_train_fwd: bad argument");
+    const Shape s = shape_of(*desc);
+    hipStream_t st = (hipStream_t)stream;
+    rocblas_handle h = handle_for(st);
+    ZEST_CHECK_ARG(h, "zest_mlp_train_fwd: cannot create a rocBLAS handle");
+    Params p;
+    for (int i = 0; i < ZEST_P_COUNT; i++) p.w[i] = params[2 * i], p.b[i] = params[2 * i + 1];
+    const long long MW = (long long)M * W;
+    float *pre[8];
+    for (int l = 0; l < 8; l++) pre[l] = saved + (size_t)l * MW;
+    float *mbuf = saved + 8 * MW, *featl = saved + 9 * MW, *hvpre = saved + 10 * MW;
+    float *actA = workspace, *actB = workspace + MW, *hp = workspace + 7 * MW + (long long)M * HW;
+    const float *xp = x, *xf = x + s.P, *xv = x + s.P + s.F;
+    const float *m = nullptr;
+    if (s.mod) {
+        RB(gemm_xwT(h, M, W, s.F, xf, s.C_in, p.w[ZEST_P_PTS_BIAS], s.F, mbuf, W, 0.f));
+        EW(bias_act_kernel, MW, mbuf, p.b[ZEST_P_PTS_BIAS], (const float *)nullptr, (float *)nullptr, MW, W, 0, 0);
+        m = mbuf;
+    }
+    float *cur = actA, *nxt = actB;
+    for (int l = 0; l < 8; l++) {
+        if (l == 0) {
+            RB(gemm_xwT(h, M, W, s.P, xp, s.C_in, p.w[0], s.P, pre[0], W, 0.f));
+        } else if (l == 5) {      // input = [pts | h]
+            RB(gemm_xwT(h, M, W, s.P, xp, s.C_in, p.w[5], W + s.P, pre[5], W, 0.f));
+            RB(gemm_xwT(h, M, W, W, cur, W, p.w[5] + s.P, W + s.P, pre[5], W, 1.f));
+        } else {
+            RB(gemm_xwT(h, M, W, W, cur, W, p.w[l], W, pre[l], W, 0.f));
+        }
+        EW(bias_act_kernel, MW, pre[l], p.b[l], m, nxt, MW, W, s.v2, 1);
+        float *t = cur;
+        cur = nxt, nxt = t;
+    }
+    // heads on the trunk output `cur`: alpha (col 3), extras (cols 4..)
+    EW(fill_kernel, (long long)M * 16, hp, (long long)M * 16, 0.f);
+    RB(gemm_xwT(h, M, 1, W, cur, W, p.w[ZEST_P_ALPHA], W, hp + 3, 16, 0.f));
+    float hb[16] = {0};
+    // biases of the heads are added below through a tiny bias vector on the device: reuse nxt[0..15]
+    if (s.head == ZEST_HEAD_BLEND) RB(gemm_xwT(h, M, 1, W, cur, W, p.w[ZEST_P_HEAD0], W, hp + 4, 16, 0.f));
+    if (s.head == ZEST_HEAD_DYNAMIC) {
+        RB(gemm_xwT(h, M, 6, W, cur, W, p.w[ZEST_P_HEAD0], W, hp + 4, 16, 0.f));
+        RB(gemm_xwT(h, M, 2, W, cur, W, p.w[ZEST_P_HEAD1], W, hp + 10, 16, 0.f));
+    }
+    (void)hb;
+    // feature -> views -> rgb
+    RB(gemm_xwT(h, M, W, W, cur, W, p.w[ZEST_P_FEATURE], W, featl, W, 0.f));
+    EW(bias_act_kernel, MW, featl, p.b[ZEST_P_FEATURE], (const float *)nullptr, (float *)nullptr, MW, W, 0, 0);
+    RB(gemm_xwT(h, M, HW, W, featl, W, p.w[ZEST_P_VIEWS], W + s.V, hvpre, HW, 0.f));
+    RB(gemm_xwT(h, M, HW, s.V, xv, s.C_in, p.w[ZEST_P_VIEWS] + W, W + s.V, hvpre, HW, 1.f));
+    EW(bias_act_kernel, (long long)M * HW, hvpre, p.b[ZEST_P_VIEWS], (const float *)nullptr, nxt, (long long)M * HW,
+       HW, 0, 1);
+    RB(gemm_xwT(h, M, 3, HW, nxt, HW, p.w[ZEST_P_RGB], HW, hp, 16, 0.f));
+    // head biases: assemble the 16-entry bias row on the device from the parameter tensors
+    {
+        float *brow = nxt + (long long)M * HW;      // 16 floats of scratch behind the view activations
+        EW(fill_kernel, 16, brow, 16, 0.f);
+        hipMemcpyAsync(brow, p.b[ZEST_P_RGB], 3 * sizeof(float), hipMemcpyDeviceToDevice, st);
+        hipMemcpyAsync(brow + 3, p.b[ZEST_P_ALPHA], sizeof(float), hipMemcpyDeviceToDevice, st);
+        if (s.head == ZEST_HEAD_BLEND)
+            hipMemcpyAsync(brow + 4, p.b[ZEST_P_HEAD0], sizeof(float), hipMemcpyDeviceToDevice, st);
+        if (s.head == ZEST_HEAD_DYNAMIC) {
+            hipMemcpyAsync(brow + 4, p.b[ZEST_P_HEAD0], 6 * sizeof(float), hipMemcpyDeviceToDevice, st);
+            hipMemcpyAsync(brow + 10, p.b[ZEST_P_HEAD1], 2 * sizeof(float), hipMemcpyDeviceToDevice, st);
+        }
+        EW(bias_act_kernel, (long long)M * 16, hp, brow, (const float *)nullptr, (float *)nullptr, (long long)M * 16,
+           16, 0, 0);
+    }
+    EW(heads_fwd_kernel, (long long)M * s.C_out, hp, M, s.C_out, s.head, s.v2, out);
+    ZEST_RETURN_LAUNCH("zest_mlp_train_fwd");
+}
+
+extern "C" int zest_mlp_train_bwd(const zest_mlp_desc *desc, const float *const *params, const float *x,
+                                  int M, const float *saved, const float *out, const float *g_out,
+                                  float *workspace, float *g_x, float *const *g_params, void *stream) {
+    ZEST_CHECK_ARG(desc && params && x && saved && out && g_out && workspace && g_params && M > 0,
+                   "zest_mlp_train_bwd: bad argument");
+    const Shape s = shape_of(*desc);
+    hipStream_t st = (hipStream_t)stream;
+    rocblas_handle h = handle_for(st);
+    ZEST_CHECK_ARG(h, "zest_mlp_train_bwd: cannot create a rocBLAS handle");
+    Params p;
+    GradParams g;
+    for (int i = 0; i < ZEST_P_COUNT; i++) {
+        p.w[i] = params[2 * i], p.b[i] = params[2 * i + 1];
+        g.w[i] = g_params[2 * i], g.b[i] = g_params[2 * i + 1];
+    }
+    const long long MW = (long long)M * W, MH = (long long)M * HW;
+    const float *pre[8];
+    for (int l = 0; l < 8; l++) pre[l] = saved + (size_t)l * MW;
+    const float *mbuf = s.mod ? saved + 8 * MW : nullptr, *featl = saved + 9 * MW, *hvpre = saved + 10 * MW;
+    float *da = workspace + 2 * MW, *db_ = workspace + 3 * MW, *act = workspace + 4 * MW, *dm = workspace + 5 * MW;
+    float *dfeat = workspace + 6 * MW, *dhv = workspace + 7 * MW, *dhp = dhv + MH, *ones = dhp + (long long)M * 16;
+    const float *xp = x, *xf = x + s.P, *xv = x + s.P + s.F;
+    float *gxp = g_x, *gxf = g_x ? g_x + s.P : nullptr;
+    EW(fill_kernel, (long long)M, ones, (long long)M, 1.f);
+    if (s.mod) EW(fill_kernel, MW, dm, MW, 0.f);
+    if (g_x) EW(fill_kernel, (long long)M * s.C_in, g_x, (long long)M * s.C_in, 0.f);
+
+    // heads: dL/d(pre-activations)
+    EW(heads_bwd_kernel, (long long)M * 16, g_out, out, M, s.C_out, s.head, s.v2, dhp);
+    // rgb_linear on hv = relu(hvpre)
+    EW(react_kernel, MH, hvpre, (const float *)nullptr, act, MH, 0);
+    RB(gemm_dw(h, M, 3, HW, dhp, 16, act, HW, g.w[ZEST_P_RGB], HW));
+    RB(col_sums(h, M, 3, dhp, 16, ones, g.b[ZEST_P_RGB]));
+    RB(gemm_dx(h, M, 3, HW, dhp, 16, p.w[ZEST_P_RGB], HW, dhv, HW, 0.f));
+    EW(act_bwd_kernel, MH, dhv, hvpre, (const float *)nullptr, (float *)nullptr, MH, 0);
+    // views_linears.0 on [feature | views]
+    RB(gemm_dw(h, M, HW, W, dhv, HW, featl, W, g.w[ZEST_P_VIEWS], W + s.V));
+    RB(gemm_dw(h, M, HW, s.V, dhv, HW, xv, s.C_in, g.w[ZEST_P_VIEWS] + W, W + s.V));
+    RB(col_sums(h, M, HW, dhv, HW, ones, g.b[ZEST_P_VIEWS]));
+    RB(gemm_dx(h, M, HW, W, dhv, HW, p.w[ZEST_P_VIEWS], W + s.V, dfeat, W, 0.f));
+    // trunk output h7 = relu(mod(pre7, m)): feature_linear, alpha and the extra heads read it
+    EW(react_kernel, MW, pre[7], mbuf, act, MW, s.v2);
+    RB(gemm_dw(h, M, W, W, dfeat, W, act, W, g.w[ZEST_P_FEATURE], W));
+    RB(col_sums(h, M, W, dfeat, W, ones, g.b[ZEST_P_FEATURE]));
+    RB(gemm_dx(h, M, W, W, dfeat, W, p.w[ZEST_P_FEATURE], W, da, W, 0.f));
+    RB(gemm_dw(h, M, 1, W, dhp + 3, 16, act, W, g.w[ZEST_P_ALPHA], W));
+    RB(col_sums(h, M, 1, dhp + 3, 16, ones, g.b[ZEST_P_ALPHA]));
+    RB(gemm_dx(h, M, 1, W, dhp + 3, 16, p.w[ZEST_P_ALPHA], W, da, W, 1.f));
+    if (s.head != ZEST_HEAD_NONE) {
+        const int n0 = s.head == ZEST_HEAD_BLEND ? 1 : 6;
+        RB(gemm_dw(h, M, n0, W, dhp + 4, 16, act, W, g.w[ZEST_P_HEAD0], W));
+        RB(col_sums(h, M, n0, dhp + 4, 16, ones, g.b[ZEST_P_HEAD0]));
+        RB(gemm_dx(h, M, n0, W, dhp + 4, 16, p.w[ZEST_P_HEAD0], W, da, W, 1.f));
+        if (s.head == ZEST_HEAD_DYNAMIC) {
+            RB(gemm_dw(h, M, 2, W, dhp + 10, 16, act, W, g.w[ZEST_P_HEAD1], W));
+            RB(col_sums(h, M, 2, dhp + 10, 16, ones, g.b[ZEST_P_HEAD1]));
+            RB(gemm_dx(h, M, 2, W, dhp + 10, 16, p.w[ZEST_P_HEAD1], W, da, W, 1.f));
+        }
+    }
+    // trunk, last layer first.  da = dL/d(act_l) on entry to layer l.
+    float *dcur = da, *dnxt = db_;
+    for (int l = 7; l >= 0; l--) {
+        EW(act_bwd_kernel, MW, dcur, pre[l], mbuf, dm, MW, s.v2);           // dcur = dL/dpre_l
+        RB(col_sums(h, M, W, dcur, W, ones, g.b[l]));
+        if (l == 0) {
+            RB(gemm_dw(h, M, W, s.P, dcur, W, xp, s.C_in, g.w[0], s.P));
+            if (g_x) RB(gemm_dx(h, M, W, s.P, dcur, W, p.w[0], s.P, gxp, s.C_in, 1.f));
+            break;
+        }
+        EW(react_kernel, MW, pre[l - 1], mbuf, act, MW, s.v2);              // input of layer l
+        if (l == 5) {
+            RB(gemm_dw(h, M, W, s.P, dcur, W, xp, s.C_in, g.w[5], W + s.P));
+            RB(gemm_dw(h, M, W, W, dcur, W, act, W, g.w[5] + s.P, W + s.P));
+            if (g_x) RB(gemm_dx(h, M, W, s.P, dcur, W, p.w[5], W + s.P, gxp, s.C_in, 1.f));
+            RB(gemm_dx(h, M, W, W, dcur, W, p.w[5] + s.P, W + s.P, dnxt, W, 0.f));
+        } else {
+            RB(gemm_dw(h, M, W, W, dcur, W, act, W, g.w[l], W));
+            RB(gemm_dx(h, M, W, W, dcur, W, p.w[l], W, dnxt, W, 0.f));
+        }
+        float *t = dcur;
+        dcur = dnxt, dnxt = t;
+    }
+    if (s.mod) {        // m = pts_bias(feats)
+        RB(gemm_dw(h, M, W, s.F, dm, W, xf, s.C_in, g.w[ZEST_P_PTS_BIAS], s.F));
+        RB(col_sums(h, M, W, dm, W, ones, g.b[ZEST_P_PTS_BIAS]));
+        if (g_x) RB(gemm_dx(h, M, W, s.F, dm, W, p.w[ZEST_P_PTS_BIAS], s.F, gxf, s.C_in, 1.f));
+    }
+    ZEST_RETURN_LAUNCH("zest_mlp_train_bwd");
+}

@@ -8,9 +8,10 @@
 
 namespace {
 
-struct RayCams {
-    float k_tgt[9], c2w_tgt[16];     // target view: intrinsics, camera-to-world
-    float w2c_ref[16], k_ref[9];     // reference view (volume frame)
+struct RayCams {                     // device pointers into the batch's camera tensors
+    const float *k_tgt, *c2w_tgt;    // target view: intrinsics [3,3], camera-to-world [4,4]
+    const float *w2c_ref, *k_ref;    // reference view (volume frame)
+    const float *nf_tgt, *nf_ref;    // (near, far) of the two views
 };
 
 // torch.linspace(0, 1, S)[i] in fp32: forward from the start for the first half, backward
@@ -45,13 +46,13 @@ __device__ __forceinline__ void ndc_of(const float *w2c, const float *K, float p
 }
 
 __global__ void build_rays_kernel(RayCams c, const float *__restrict__ xs, const float *__restrict__ ys,
-                                  const float *__restrict__ t_rand, int R, int S, float near_tgt,
-                                  float far_tgt, float near_ref, float far_ref, int pad, int W, int H,
+                                  const float *__restrict__ t_rand, int R, int S, int pad, int W, int H,
                                   float *__restrict__ rays_dir, float *__restrict__ depth,
                                   float *__restrict__ pts, float *__restrict__ ndc) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= R * S) return;
     const int r = m / S, s = m % S;
+    const float near_tgt = c.nf_tgt[0], far_tgt = c.nf_tgt[1], near_ref = c.nf_ref[0], far_ref = c.nf_ref[1];
     const float dx = (xs[r] - c.k_tgt[2]) / c.k_tgt[0], dy = (ys[r] - c.k_tgt[5]) / c.k_tgt[4];
     float d[3];
 #pragma unroll
@@ -75,50 +76,40 @@ __global__ void build_rays_kernel(RayCams c, const float *__restrict__ xs, const
     ndc[3 * m] = o[0], ndc[3 * m + 1] = o[1], ndc[3 * m + 2] = o[2];
 }
 
-__global__ void ndc_kernel(RayCams c, int has_w2c, const float *__restrict__ pts, int M, float inv_w,
-                           float inv_h, float near, float far, int pad, int lindisp,
-                           float *__restrict__ out) {
+__global__ void ndc_kernel(const float *__restrict__ w2c, const float *__restrict__ K,
+                           const float *__restrict__ pts, int M, float inv_w, float inv_h, float near,
+                           float far, int pad, int lindisp, float *__restrict__ out) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
     float o[3];
-    ndc_of(has_w2c ? c.w2c_ref : nullptr, c.k_ref, pts[3 * m], pts[3 * m + 1], pts[3 * m + 2], inv_w, inv_h,
-           near, far, pad, lindisp, o);
+    ndc_of(w2c, K, pts[3 * m], pts[3 * m + 1], pts[3 * m + 2], inv_w, inv_h, near, far, pad, lindisp, o);
     out[3 * m] = o[0], out[3 * m + 1] = o[1], out[3 * m + 2] = o[2];
 }
 
 }  // namespace
 
-// Host matrices: the four small camera matrices are passed by value (host pointers), like
-// the reference which indexes them out of the batch dict on the host side.
 extern "C" int zest_build_rays_fwd(const float *xs, const float *ys, const float *t_rand, int R, int S,
-                                   const float *k_tgt_host, const float *c2w_tgt_host,
-                                   const float *w2c_ref_host, const float *k_ref_host, float near_tgt,
-                                   float far_tgt, float near_ref, float far_ref, int pad, int W, int H,
-                                   float *rays_dir, float *depth, float *pts, float *ndc, void *stream) {
-    ZEST_CHECK_ARG(xs && ys && k_tgt_host && c2w_tgt_host && w2c_ref_host && k_ref_host && rays_dir &&
-                       depth && pts && ndc, "zest_build_rays_fwd: null argument");
+                                   const float *k_tgt, const float *c2w_tgt, const float *w2c_ref,
+                                   const float *k_ref, const float *near_far_tgt,
+                                   const float *near_far_ref, int pad, int W, int H, float *rays_dir,
+                                   float *depth, float *pts, float *ndc, void *stream) {
+    ZEST_CHECK_ARG(xs && ys && k_tgt && c2w_tgt && w2c_ref && k_ref && near_far_tgt && near_far_ref &&
+                       rays_dir && depth && pts && ndc, "zest_build_rays_fwd: null argument");
     ZEST_CHECK_ARG(R >= 0 && S >= 1 && W >= 2 && H >= 2 && pad >= 0, "zest_build_rays_fwd: bad shape");
     if (R == 0) return 0;
-    RayCams c;
-    for (int i = 0; i < 9; i++) c.k_tgt[i] = k_tgt_host[i], c.k_ref[i] = k_ref_host[i];
-    for (int i = 0; i < 16; i++) c.c2w_tgt[i] = c2w_tgt_host[i], c.w2c_ref[i] = w2c_ref_host[i];
+    const RayCams c{k_tgt, c2w_tgt, w2c_ref, k_ref, near_far_tgt, near_far_ref};
     hipLaunchKernelGGL(build_rays_kernel, dim3(zest_div_up((long long)R * S, 256)), dim3(256), 0,
-                       (hipStream_t)stream, c, xs, ys, t_rand, R, S, near_tgt, far_tgt, near_ref, far_ref,
-                       pad, W, H, rays_dir, depth, pts, ndc);
+                       (hipStream_t)stream, c, xs, ys, t_rand, R, S, pad, W, H, rays_dir, depth, pts, ndc);
     ZEST_RETURN_LAUNCH("zest_build_rays_fwd");
 }
 
-extern "C" int zest_ndc_fwd(const float *pts, int M, const float *w2c_host, const float *k_host,
-                            float inv_w, float inv_h, float near, float far, int pad, int lindisp,
-                            float *out, void *stream) {
-    ZEST_CHECK_ARG(pts && k_host && out, "zest_ndc_fwd: null argument");
+extern "C" int zest_ndc_fwd(const float *pts, int M, const float *w2c, const float *k, float inv_w,
+                            float inv_h, float near, float far, int pad, int lindisp, float *out,
+                            void *stream) {
+    ZEST_CHECK_ARG(pts && k && out, "zest_ndc_fwd: null argument");
     ZEST_CHECK_ARG(M >= 0 && pad >= 0, "zest_ndc_fwd: bad shape");
     if (M == 0) return 0;
-    RayCams c = {};
-    for (int i = 0; i < 9; i++) c.k_ref[i] = k_host[i];
-    if (w2c_host)
-        for (int i = 0; i < 16; i++) c.w2c_ref[i] = w2c_host[i];
-    hipLaunchKernelGGL(ndc_kernel, dim3(zest_div_up(M, 256)), dim3(256), 0, (hipStream_t)stream, c,
-                       w2c_host ? 1 : 0, pts, M, inv_w, inv_h, near, far, pad, lindisp, out);
+    hipLaunchKernelGGL(ndc_kernel, dim3(zest_div_up(M, 256)), dim3(256), 0, (hipStream_t)stream, w2c, k, pts,
+                       M, inv_w, inv_h, near, far, pad, lindisp, out);
     ZEST_RETURN_LAUNCH("zest_ndc_fwd");
 }

@@ -93,9 +93,8 @@ class _MlpBase(nn.Module):
 
     def zest_forward(self, x, precision=None):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError(
-                "zest MLP: backward kernels are not built yet (SURVEY.md 8(f) next-2); "
-                "call under torch.no_grad()")
+            raise RuntimeError("zest MLP: use MVSNeRF.forward (it owns the `nerf.` parameter names the "
+                               "training path needs)")
         desc = self._desc()
         prec = resolve_precision() if precision is None else precision
         return zest_hip.mlp_fwd(desc, prec, self.packed(prec), x)
@@ -181,4 +180,7 @@ class MVSNeRF(nn.Module):
         return self.nerf.zest_forward(x, precision)
 
     def forward(self, x):
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            import zest_autograd
+            return zest_autograd.mlp_apply(self, x)          # fp32 training path (HIP fwd + bwd)
         return self.nerf(x)

@@ -4,8 +4,9 @@
 (/root/reference/renderer.py:579-626); so do the helpers other reference modules import
 (`raw2outputs`, `raw2outputs_blending`, `raw2alpha`, `depth2dist`, `compute_2d_prob`).
 All device work goes through the C ABI (include/zest_render.h); there is no PyTorch
-restatement in this package.  Gradients are not provided yet: calls made with autograd
-recording raise (backward kernels are SURVEY.md 8(f) next-2).
+restatement in this package.  When autograd is recording and a parameter, a volume or the
+sample coordinates want a gradient, every stage runs as an autograd.Function whose forward
+and backward are HIP kernels (zest_autograd.py, fp32); otherwise the inference kernels run.
 
 Two execution plans:
   * complete  - per-sample tensors in HBM (encode -> MLP -> composite kernels); returns
@@ -83,12 +84,16 @@ def raw2alpha(sigma, dist):
 def raw2outputs(raw, z_vals, dists, white_bkgd=False, raw_noise_std=0):
     """[N,R,S,4] -> rgb_map, disp_map, acc_map, weights, depth_map, alpha
     (reference renderer.py:115-164)."""
-    _no_grad_only(raw)
     lead, S = z_vals.shape[:-1], z_vals.shape[-1]
     z, pdir = _split_dists(z_vals, dists)
     noise = _draw_noise(z_vals.shape, z_vals.device).reshape(-1, S) if raw_noise_std > 0 else None
-    rgb, disp, acc, w, depth, a = zest_hip.composite(raw.reshape(-1, S, 4), z, pdir, noise,
-                                                     float(raw_noise_std), bool(white_bkgd))
+    if torch.is_grad_enabled() and raw.requires_grad:
+        import zest_autograd as za
+        rgb, disp, acc, w, depth, a = za.CompositeFn.apply(raw.reshape(-1, S, 4).contiguous(), z, pdir, noise,
+                                                           float(raw_noise_std), bool(white_bkgd))
+    else:
+        rgb, disp, acc, w, depth, a = zest_hip.composite(raw.reshape(-1, S, 4), z, pdir, noise,
+                                                         float(raw_noise_std), bool(white_bkgd))
     return (rgb.view(*lead, 3), disp.view(*lead), acc.view(*lead), w.view(*lead, S),
             depth.view(*lead), a.view(*lead, S))
 
@@ -96,13 +101,17 @@ def raw2outputs(raw, z_vals, dists, white_bkgd=False, raw_noise_std=0):
 def raw2outputs_blending(raw_dy, raw_rigid, raw_blend_w, z_vals, dists, raw_noise_std=0):
     """-> rgb_map, depth_map, rgb_map_fg, depth_map_fg, weights_fg, weights_dy
     (reference renderer.py:166-219)."""
-    _no_grad_only(raw_dy, raw_rigid, raw_blend_w)
     lead, S = z_vals.shape[:-1], z_vals.shape[-1]
     z, pdir = _split_dists(z_vals, dists)
     noise = _draw_noise(z_vals.shape, z_vals.device).reshape(-1, S) if raw_noise_std > 0 else None
-    rgb, depth, rgb_fg, depth_fg, w_fg, w_dy, _ = zest_hip.composite_blend(
-        raw_dy.reshape(-1, S, 4), raw_rigid.reshape(-1, S, 4), raw_blend_w.reshape(-1, S), z, pdir,
-        noise, float(raw_noise_std))
+    args3 = (raw_dy.reshape(-1, S, 4), raw_rigid.reshape(-1, S, 4), raw_blend_w.reshape(-1, S))
+    if torch.is_grad_enabled() and any(t.requires_grad for t in args3):
+        import zest_autograd as za
+        rgb, depth, rgb_fg, depth_fg, w_fg, w_dy, _ = za.BlendFn.apply(
+            *[t.contiguous() for t in args3], z, pdir, noise, float(raw_noise_std))
+    else:
+        rgb, depth, rgb_fg, depth_fg, w_fg, w_dy, _ = zest_hip.composite_blend(*args3, z, pdir, noise,
+                                                                               float(raw_noise_std))
     return (rgb.view(*lead, 3), depth.view(*lead), rgb_fg.view(*lead, 3), depth_fg.view(*lead),
             w_fg.view(*lead, S), w_dy.view(*lead, S))
 
@@ -192,17 +201,22 @@ def rendering(args, rays_pts, rays_ndc, depth_candidates, rays_dir,
         raise NotImplementedError("zest renderer: use_color_volume is never set by the reference configs")
     if rays_ndc.shape[0] != 1:
         raise RuntimeError("zest renderer: image batch must be 1 (reference train.py:307)")
-    _no_grad_only(rays_pts, rays_ndc, depth_candidates, rays_dir, volume_feature_static,
-                  volume_feature_dynamic)
     net_s = _net(network_fn, "network_fn")
     _check_embedders(embedding_pts, embedding_dir, 3)
     prec = resolve_precision(args)
     N, R, S, _ = rays_ndc.shape
     ndc, pts = rays_ndc[0].float().contiguous(), rays_pts[0].float().contiguous()
     z, dirs = depth_candidates[0].float().contiguous(), rays_dir[0].float().contiguous()
-    if torch.is_grad_enabled() and any(p.requires_grad for p in net_s.parameters()):
-        raise NotImplementedError("zest renderer: backward kernels are not built yet "
-                                  "(SURVEY.md 8(f) next-2); call under torch.no_grad()")
+    # Training path: autograd recording and something upstream wants a gradient.  Every stage
+    # then runs as an autograd.Function with HIP forward and backward (zest_autograd.py), fp32.
+    def wants_grad(*ts):
+        return any(t is not None and torch.is_tensor(t) and t.requires_grad for t in ts)
+    train = torch.is_grad_enabled() and (
+        wants_grad(rays_ndc, volume_feature_static, volume_feature_dynamic)
+        or any(p.requires_grad for p in net_s.parameters())
+        or (network_fn_dy is not None and any(p.requires_grad for p in network_fn_dy.parameters())))
+    if train:
+        import zest_autograd as za
 
     if prec == zest_hip.PREC_BF16 and getattr(args, "zest_maps_only", False) and (val or not scene_flow):
         return _render_maps_fused(rays_ndc, ndc, pts, z, dirs, net_s, network_fn_dy, scene_flow,
@@ -211,19 +225,32 @@ def rendering(args, rays_pts, rays_ndc, depth_candidates, rays_dir,
                                   embedding_dir, ref_frame_idx, white_bkgd, raw_noise_std)
 
     def mlp(net, x):
+        if train:
+            return za.mlp_apply(net, x)
         return zest_hip.mlp_fwd(net.desc(), prec, net.packed(prec), x)
+
+    def encode(views, volume, ndc3, t=None):
+        if train:
+            return za.EncodeFn.apply(ndc3, volume, views, pts, dirs, None if t is None else float(t))
+        return views.encode(ndc3, pts, dirs, t)
+
+    def composite(raw4, nz, std, white):
+        if train:
+            return za.CompositeFn.apply(raw4.contiguous(), z, dirs, nz, float(std), bool(white))
+        return zest_hip.composite(raw4, z, dirs, nz, float(std), bool(white))
 
     def noise():
         return _draw_noise((1, R, S), ndc.device)[0] if raw_noise_std > 0 else None
 
     # ---- static NeRF (reference render_static, renderer.py:322-373)
     vs = _Views(volume_feature_static, imgs, im_cam_mat)
-    x_s = vs.encode(ndc, pts, dirs)
+    if train and rays_ndc.requires_grad:
+        ndc = rays_ndc[0].float()
+    x_s = encode(vs, volume_feature_static, ndc)
     raw_s = mlp(net_s, x_s)
     raw_rgba = raw_s[..., :4]
     blend = raw_s[..., 4] if scene_flow else None
-    rgb_map, _, _, weights, depth_map, alpha = zest_hip.composite(
-        raw_rgba, z, dirs, noise(), float(raw_noise_std), bool(white_bkgd))
+    rgb_map, _, _, weights, depth_map, alpha = composite(raw_rgba, noise(), raw_noise_std, white_bkgd)
     F = net_s.in_ch_feat if vs.vol_cl is not None else 0
     input_feat = x_s[None, ..., 63:63 + F] if F else None
     ret = {'rgb_map': rgb_map[None], 'depth_map': depth_map[None], 'raw_rgba': raw_rgba[None],
@@ -238,20 +265,25 @@ def rendering(args, rays_pts, rays_ndc, depth_candidates, rays_dir,
     vd = _Views(volume_feature_dynamic, neighbour_frames, nb_cam_mat)
 
     def dyn_pass(ndc3, t):
-        return mlp(net_d, vd.encode(ndc3, pts, dirs, float(t)))
+        return mlp(net_d, encode(vd, volume_feature_dynamic, ndc3, float(t)))
 
     raw_ref = dyn_pass(ndc, ref_frame_idx)
     sf_prev, sf_post = raw_ref[..., 4:7], raw_ref[..., 7:10]
     prob_prev, prob_post = raw_ref[..., 10], raw_ref[..., 11]
-    rgb_ref, depth_ref, rgb_fg, depth_fg, w_fg, w_dd, dd_sum = zest_hip.composite_blend(
-        raw_ref[..., :4], raw_rgba, blend, z, dirs, noise(), float(raw_noise_std))
+    if train:
+        rgb_ref, depth_ref, rgb_fg, depth_fg, w_fg, w_dd, dd_sum = za.BlendFn.apply(
+            raw_ref[..., :4].contiguous(), raw_rgba.contiguous(), blend.contiguous(), z, dirs, noise(),
+            float(raw_noise_std))
+    else:
+        rgb_ref, depth_ref, rgb_fg, depth_fg, w_fg, w_dd, dd_sum = zest_hip.composite_blend(
+            raw_ref[..., :4], raw_rgba, blend, z, dirs, noise(), float(raw_noise_std))
     ret.update({'rgb_map_ref': rgb_ref[None], 'depth_map_ref': depth_ref[None],
                 'rgb_map_ref_dy': rgb_fg[None], 'depth_map_ref_dy': depth_fg[None],
                 'weights_map_dd': dd_sum[None]})
     if val:
         return ret
     ret.update({'raw_sf_ref2prev': sf_prev[None], 'raw_sf_ref2post': sf_post[None],
-                'raw_pts_ref': rays_ndc[..., :3], 'weights_ref_dy': w_fg[None],
+                'raw_pts_ref': ndc[None] if train else rays_ndc[..., :3], 'weights_ref_dy': w_fg[None],
                 'raw_blend_w': blend[None], 'raw_prob_ref2prev': prob_prev[None],
                 'raw_prob_ref2post': prob_post[None]})
     # Neighbour frames.  Reference quirk kept on purpose (renderer.py:478-479, 505-506,
@@ -261,8 +293,13 @@ def rendering(args, rays_pts, rays_ndc, depth_candidates, rays_dir,
     step = 1. / num_frames * 2.
 
     def nb_render(raw):
-        rgb, _, _, w, _, _ = zest_hip.composite(raw[..., :4], z, dirs, None, 0.0, white_nb)
+        rgb, _, _, w, _, _ = composite(raw[..., :4], None, 0.0, white_nb)
         return rgb, w
+
+    def prob2d(w, p):
+        if train:
+            return za.Prob2dFn.apply(w.detach(), p.contiguous())
+        return zest_hip.weighted_complement_sum(w, p)
 
     ndc_prev = ndc + sf_prev
     raw_prev = dyn_pass(ndc_prev, ref_frame_idx - step)
@@ -273,8 +310,8 @@ def rendering(args, rays_pts, rays_ndc, depth_candidates, rays_dir,
     ret.update({'raw_pts_prev': ndc_prev[None], 'raw_sf_prev2ref': raw_prev[None, ..., 7:10],
                 'rgb_map_prev_dy': rgb_prev[None], 'raw_pts_post': ndc_post[None],
                 'raw_sf_post2ref': raw_post[None, ..., 4:7], 'rgb_map_post_dy': rgb_post[None],
-                'prob_map_prev': zest_hip.weighted_complement_sum(w_prev, prob_prev)[None],
-                'prob_map_post': zest_hip.weighted_complement_sum(w_post, prob_post)[None]})
+                'prob_map_prev': prob2d(w_prev, prob_prev)[None],
+                'prob_map_post': prob2d(w_post, prob_post)[None]})
     if chain_bwd:
         ndc_pp, t_pp = ndc_prev + raw_prev[..., 4:7], ref_frame_idx - 2. / num_frames * 2.
     else:

@@ -162,8 +162,7 @@ def build_rays_base(imgs, depths, w2cs, c2ws, intrinsics, near_fars, N_samples, 
     t_rand = _draw_uniform((R, N_samples), device) if stratified else None
     d, z, pts, ndc = zest_hip.build_rays(
         xs, ys, t_rand, N_samples, intrinsics[0, -1], c2ws[0, -1], w2cs[0, ref_idx], intrinsics[0, ref_idx],
-        float(near_fars[0, -1, 0]), float(near_fars[0, -1, 1]), float(near_fars[0, ref_idx, 0]),
-        float(near_fars[0, ref_idx, 1]), pad, W, H)
+        near_fars[0, -1], near_fars[0, ref_idx], pad, W, H)
     t_vals = torch.linspace(0., 1., steps=N_samples).view(1, N_samples).to(device)
     return (pts[None], d[None], color, ndc[None], z[None], rays_depth_gt, t_vals, gt[0], gt[1], gt[2], gt[3])
 

@@ -1,0 +1,135 @@
+"""Autograd wiring of the training path: each stage of `rendering` is a torch.autograd.Function
+whose forward AND backward are HIP kernels behind the C ABI (plus rocBLAS sgemm inside the
+MLP).  Gradients exist exactly where the reference's training graph has them:
+
+  EncodeFn     d/d(volume coordinates)  - through the positional encoding and the trilinear
+               lookup (scene-flow displaced points, renderer.py:461,488) - and d/d(encoding
+               volume) (MVSNet trains through it); world points, images, cameras, directions
+               are data.
+  MlpFn        d/d(input point-encoding and feature columns) and d/d(every parameter).
+  CompositeFn, BlendFn   d/d(raw predictions[, blend weight]); depth samples are data.
+  Prob2dFn     compute_2d_prob: the weights are detached in the reference (renderer.py:31).
+
+The training path computes in fp32 whatever `precision` says (the bf16 engine is inference only).
+"""
+import torch
+from torch.autograd import Function
+
+import zest_hip
+
+
+class EncodeFn(Function):
+    @staticmethod
+    def forward(ctx, ndc, volume, views, pts, dirs, t):
+        """ndc [R,S,3]; volume: the caller's [1,8,D,H,W] tensor or None; views: renderer._Views."""
+        x = views.encode(ndc, pts, dirs, t)
+        ctx.views, ctx.t = views, t
+        ctx.vol_shape = None if volume is None else tuple(volume.shape)
+        ctx.save_for_backward(ndc)
+        return x
+
+    @staticmethod
+    def backward(ctx, g_x):
+        (ndc,) = ctx.saved_tensors
+        v = ctx.views
+        want_vol = ctx.vol_shape is not None and ctx.needs_input_grad[1]
+        V = v.imgs_cl.shape[0] if v.imgs_cl is not None else 0
+        g_ndc, g_vol_cl = zest_hip.encode_bwd(g_x.contiguous(), ndc, ctx.t, v.vol_cl, V, want_vol)
+        g_vol = zest_hip.volume_from_cl(g_vol_cl).view(ctx.vol_shape) if want_vol else None
+        return g_ndc, g_vol, None, None, None, None
+
+
+class MlpFn(Function):
+    @staticmethod
+    def forward(ctx, x, desc, slots, *params):
+        """params: the (weight, bias) tensors of the slots in `slots` (ZEST_P_* order)."""
+        table = [None] * (2 * zest_hip.P_COUNT)
+        for i, s in enumerate(slots):
+            table[2 * s], table[2 * s + 1] = params[2 * i], params[2 * i + 1]
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        out, saved = zest_hip.mlp_train_fwd(desc, table, x2)
+        ctx.desc, ctx.slots, ctx.lead = desc, slots, lead
+        ctx.save_for_backward(x2, saved, out, *params)
+        return out.view(*lead, desc.out_ch)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x2, saved, out, *params = ctx.saved_tensors
+        table = [None] * (2 * zest_hip.P_COUNT)
+        for i, s in enumerate(ctx.slots):
+            table[2 * s], table[2 * s + 1] = params[2 * i], params[2 * i + 1]
+        g_x, grads = zest_hip.mlp_train_bwd(ctx.desc, table, x2, saved, out,
+                                            g_out.reshape(-1, ctx.desc.out_ch).contiguous(),
+                                            want_gx=ctx.needs_input_grad[0])
+        gp = []
+        for s in ctx.slots:
+            gp += [grads[2 * s], grads[2 * s + 1]]
+        return (g_x.view(*ctx.lead, -1) if g_x is not None else None, None, None, *gp)
+
+
+class CompositeFn(Function):
+    @staticmethod
+    def forward(ctx, raw, z, dirs, noise, noise_std, white_bkgd):
+        rgb, disp, acc, w, depth, alpha = zest_hip.composite(raw, z, dirs, noise, noise_std, white_bkgd)
+        ctx.cfg = (noise_std, white_bkgd)
+        ctx.save_for_backward(raw, z, dirs, noise if noise is not None else raw.new_empty(0))
+        ctx.mark_non_differentiable(disp, alpha)
+        return rgb, disp, acc, w, depth, alpha
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_disp, g_acc, g_w, g_depth, g_alpha):
+        raw, z, dirs, noise = ctx.saved_tensors
+        g_raw = zest_hip.composite_bwd(raw, z, dirs, noise if noise.numel() else None, ctx.cfg[0], ctx.cfg[1],
+                                       g_rgb, g_depth, g_acc, g_w)
+        return g_raw, None, None, None, None, None
+
+
+class BlendFn(Function):
+    @staticmethod
+    def forward(ctx, raw_dy, raw_st, blend, z, dirs, noise, noise_std):
+        rgb, depth, rgb_fg, depth_fg, w_fg, w_dy, dd = zest_hip.composite_blend(raw_dy, raw_st, blend, z, dirs,
+                                                                                noise, noise_std)
+        ctx.noise_std = noise_std
+        ctx.save_for_backward(raw_dy, raw_st, blend, z, dirs, noise if noise is not None else z.new_empty(0))
+        ctx.mark_non_differentiable(dd)
+        return rgb, depth, rgb_fg, depth_fg, w_fg, w_dy, dd
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth, g_rgb_fg, g_depth_fg, g_wfg, g_wd, g_dd):
+        raw_dy, raw_st, blend, z, dirs, noise = ctx.saved_tensors
+        g_dy, g_st, g_b = zest_hip.composite_blend_bwd(raw_dy, raw_st, blend, z, dirs,
+                                                       noise if noise.numel() else None, ctx.noise_std, g_rgb,
+                                                       g_depth, g_rgb_fg, g_depth_fg, g_wfg, g_wd)
+        return g_dy, g_st, g_b, None, None, None, None
+
+
+class Prob2dFn(Function):
+    @staticmethod
+    def forward(ctx, weights, prob):
+        ctx.save_for_backward(weights)
+        return zest_hip.weighted_complement_sum(weights, prob)
+
+    @staticmethod
+    def backward(ctx, g):
+        (w,) = ctx.saved_tensors
+        return None, -(g[:, None] * w)
+
+
+def mlp_apply(net, x):
+    """Training forward of a zest networks.MVSNeRF on x [..., C_in] with autograd."""
+    mod = net.nerf
+    desc = mod._desc()
+    named = dict(mod.named_parameters())
+    slots, params = [], []
+    for name, slot in zest_hip._PARAM_SLOTS:
+        if name == "pts_bias" and not desc.use_feat:
+            continue
+        slots.append(slot)
+        params += [named[name + ".weight"], named[name + ".bias"]]
+    extra = {zest_hip.HEAD_BLEND: [("w_linear", 13)],
+             zest_hip.HEAD_DYNAMIC: [("sf_linear", 13), ("prob_linear", 14)]}.get(desc.head, [])
+    for name, slot in extra:
+        slots.append(slot)
+        params += [named[name + ".weight"], named[name + ".bias"]]
+    return MlpFn.apply(x, desc, tuple(slots), *params)

@@ -57,9 +57,19 @@ _SIGS = {
     "zest_color_lookup_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "zest_encode_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp, _i, _i, _i, _vp, _i, _i, _i,
                              _vp, _vp, _vp, _vp]),
-    "zest_build_rays_fwd": (_i, [_vp, _vp, _vp, _i, _i, _fp, _fp, _fp, _fp, _f, _f, _f, _f, _i, _i, _i,
+    "zest_build_rays_fwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i,
                                  _vp, _vp, _vp, _vp, _vp]),
-    "zest_ndc_fwd": (_i, [_vp, _i, _fp, _fp, _f, _f, _f, _f, _i, _i, _vp, _vp]),
+    "zest_ndc_fwd": (_i, [_vp, _i, _vp, _vp, _f, _f, _f, _f, _i, _i, _vp, _vp]),
+    "zest_composite_bwd": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "zest_composite_blend_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                                      _vp, _vp, _vp, _vp]),
+    "zest_encode_bwd": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "zest_volume_from_cl": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "zest_mlp_train_saved_floats": (_sz, [C.POINTER(MlpDesc), _i]),
+    "zest_mlp_train_workspace_floats": (_sz, [C.POINTER(MlpDesc), _i]),
+    "zest_mlp_train_fwd": (_i, [C.POINTER(MlpDesc), C.POINTER(_vp), _vp, _i, _vp, _vp, _vp, _vp]),
+    "zest_mlp_train_bwd": (_i, [C.POINTER(MlpDesc), C.POINTER(_vp), _vp, _i, _vp, _vp, _vp, _vp, _vp,
+                                C.POINTER(_vp), _vp]),
     "zest_mlp_packed_bytes": (_sz, [C.POINTER(MlpDesc), _i]),
     "zest_mlp_pack": (_i, [C.POINTER(MlpDesc), _i, C.POINTER(_vp), _vp, _vp]),
     "zest_mlp_fwd": (_i, [C.POINTER(MlpDesc), _i, _vp, _vp, _i, _vp, _vp]),
@@ -239,37 +249,111 @@ def encode(ndc, pts, rays_dir, t=None, vol_cl=None, imgs_cl=None, w2cs=None, int
 
 
 # ----------------------------------------------------------------------------- ray sampling
-def _host_mat(t, n):
-    """Small camera matrix -> ctypes float array (host)."""
-    v = t.detach().reshape(-1).float().cpu().tolist()
-    if len(v) != n:
-        raise RuntimeError("zest_hip: expected %d matrix entries, got %d" % (n, len(v)))
-    return (C.c_float * n)(*v)
-
-
-def build_rays(xs, ys, t_rand, S, k_tgt, c2w_tgt, w2c_ref, k_ref, near_tgt, far_tgt, near_ref, far_ref,
-               pad, W, H):
-    """xs, ys [R] pixel coordinates (device) -> rays_dir [R,3], depth [R,S], pts, ndc [R,S,3]."""
+def build_rays(xs, ys, t_rand, S, k_tgt, c2w_tgt, w2c_ref, k_ref, nf_tgt, nf_ref, pad, W, H):
+    """xs, ys [R] pixel coordinates; camera matrices and (near, far) pairs as device tensors
+    (views into the batch dict) -> rays_dir [R,3], depth [R,S], pts, ndc [R,S,3]."""
     xs, ys, t_rand = _dev(xs, "xs"), _dev(ys, "ys"), _dev(t_rand, "t_rand")
+    mats = [_dev(m, "camera") for m in (k_tgt, c2w_tgt, w2c_ref, k_ref, nf_tgt, nf_ref)]
     R = xs.numel()
     o = lambda *s: torch.empty(*s, device=xs.device, dtype=torch.float32)
     d, z, pts, ndc = o(R, 3), o(R, S), o(R, S, 3), o(R, S, 3)
-    _check(lib().zest_build_rays_fwd(_ptr(xs), _ptr(ys), _ptr(t_rand), R, int(S), _host_mat(k_tgt, 9),
-                                     _host_mat(c2w_tgt, 16), _host_mat(w2c_ref, 16), _host_mat(k_ref, 9),
-                                     float(near_tgt), float(far_tgt), float(near_ref), float(far_ref),
+    _check(lib().zest_build_rays_fwd(_ptr(xs), _ptr(ys), _ptr(t_rand), R, int(S), *[_ptr(m) for m in mats],
                                      int(pad), int(W), int(H), _ptr(d), _ptr(z), _ptr(pts), _ptr(ndc),
                                      _stream(xs)), "zest_build_rays_fwd")
     return d, z, pts, ndc
 
 
 def ndc_coordinate(pts, w2c, k, inv_w, inv_h, near, far, pad=0, lindisp=False):
-    pts = _dev(pts, "pts")
+    pts, w2c, k = _dev(pts, "pts"), _dev(w2c, "w2c"), _dev(k, "k")
     M = pts.numel() // 3
     out = torch.empty_like(pts)
-    _check(lib().zest_ndc_fwd(_ptr(pts), M, _host_mat(w2c, 16) if w2c is not None else None,
-                              _host_mat(k, 9), float(inv_w), float(inv_h), float(near), float(far),
-                              int(pad), int(bool(lindisp)), _ptr(out), _stream(pts)), "zest_ndc_fwd")
+    _check(lib().zest_ndc_fwd(_ptr(pts), M, _ptr(w2c), _ptr(k), float(inv_w), float(inv_h), float(near),
+                              float(far), int(pad), int(bool(lindisp)), _ptr(out), _stream(pts)),
+           "zest_ndc_fwd")
     return out
+
+
+def composite_bwd(raw, z, rays_dir, noise, noise_std, white_bkgd, g_rgb, g_depth, g_acc, g_weights):
+    raw, z, rays_dir, noise = _dev(raw, "raw"), _dev(z, "z"), _dev(rays_dir, "rays_dir"), _dev(noise, "noise")
+    gs = [_dev(g, "grad") for g in (g_rgb, g_depth, g_acc, g_weights)]
+    R, S = z.shape
+    g_raw = torch.empty(R, S, 4, device=z.device, dtype=torch.float32)
+    _check(lib().zest_composite_bwd(_ptr(raw), _ptr(z), _ptr(rays_dir), _ptr(noise), float(noise_std),
+                                    int(bool(white_bkgd)), R, S, *[_ptr(g) for g in gs], _ptr(g_raw),
+                                    _stream(z)), "zest_composite_bwd")
+    return g_raw
+
+
+def composite_blend_bwd(raw_dy, raw_st, blend, z, rays_dir, noise, noise_std, g_rgb, g_depth, g_rgb_fg,
+                        g_depth_fg, g_wfg, g_wd):
+    raw_dy, raw_st, blend = _dev(raw_dy, "raw_dy"), _dev(raw_st, "raw_st"), _dev(blend, "blend")
+    z, rays_dir, noise = _dev(z, "z"), _dev(rays_dir, "rays_dir"), _dev(noise, "noise")
+    gs = [_dev(g, "grad") for g in (g_rgb, g_depth, g_rgb_fg, g_depth_fg, g_wfg, g_wd)]
+    R, S = z.shape
+    o = lambda *s: torch.empty(*s, device=z.device, dtype=torch.float32)
+    g_dy, g_st, g_b = o(R, S, 4), o(R, S, 4), o(R, S)
+    _check(lib().zest_composite_blend_bwd(_ptr(raw_dy), _ptr(raw_st), _ptr(blend), _ptr(z), _ptr(rays_dir),
+                                          _ptr(noise), float(noise_std), R, S, *[_ptr(g) for g in gs],
+                                          _ptr(g_dy), _ptr(g_st), _ptr(g_b), _stream(z)),
+           "zest_composite_blend_bwd")
+    return g_dy, g_st, g_b
+
+
+# ------------------------------------------------------------------- training path (backward)
+def encode_bwd(g_x, ndc, t, vol_cl, V, want_vol_grad):
+    """-> g_ndc [R,S,3], g_vol_cl [D,H,W,8] or None."""
+    g_x, ndc = _dev(g_x, "g_x"), _dev(ndc, "ndc")
+    R, S, _ = ndc.shape
+    D = Hv = Wv = 0
+    g_vol = None
+    if vol_cl is not None:
+        D, Hv, Wv, _ = vol_cl.shape
+        if want_vol_grad:
+            g_vol = torch.zeros_like(vol_cl)
+    g_ndc = torch.empty_like(ndc)
+    _check(lib().zest_encode_bwd(_ptr(g_x), _ptr(ndc), R, S, int(t is not None), float(t) if t is not None else 0.0,
+                                 _ptr(vol_cl), D, Hv, Wv, int(V), _ptr(g_ndc), _ptr(g_vol), _stream(ndc)),
+           "zest_encode_bwd")
+    return g_ndc, g_vol
+
+
+def volume_from_cl(vol_cl):
+    D, H, W, _ = vol_cl.shape
+    out = torch.empty(1, 8, D, H, W, device=vol_cl.device, dtype=torch.float32)
+    _check(lib().zest_volume_from_cl(_ptr(vol_cl), D, H, W, _ptr(out), _stream(vol_cl)), "zest_volume_from_cl")
+    return out
+
+
+def _ptr_table(tensors):
+    return (_vp * (2 * P_COUNT))(*[_ptr(t) for t in tensors])
+
+
+def mlp_train_fwd(desc, params, x):
+    """params: 2*P_COUNT tensors-or-None.  -> out [M,C_out], saved (opaque activation stash)."""
+    x = _dev(x, "x")
+    M = x.numel() // x.shape[-1]
+    L = lib()
+    saved = torch.empty(int(L.zest_mlp_train_saved_floats(C.byref(desc), M)), device=x.device)
+    work = torch.empty(int(L.zest_mlp_train_workspace_floats(C.byref(desc), M)), device=x.device)
+    out = torch.empty(*x.shape[:-1], desc.out_ch, device=x.device, dtype=torch.float32)
+    keep = [(_dev(p, "param") if p is not None else None) for p in params]
+    _check(L.zest_mlp_train_fwd(C.byref(desc), _ptr_table(keep), _ptr(x), M, _ptr(saved), _ptr(work), _ptr(out),
+                                _stream(x)), "zest_mlp_train_fwd")
+    return out, saved
+
+
+def mlp_train_bwd(desc, params, x, saved, out, g_out, want_gx=True):
+    """-> g_x [.., C_in] or None, list of 2*P_COUNT parameter gradients (None where absent)."""
+    x, g_out = _dev(x, "x"), _dev(g_out, "g_out")
+    M = x.numel() // x.shape[-1]
+    L = lib()
+    work = torch.empty(int(L.zest_mlp_train_workspace_floats(C.byref(desc), M)), device=x.device)
+    keep = [(_dev(p, "param") if p is not None else None) for p in params]
+    grads = [(torch.empty_like(p) if p is not None else None) for p in keep]
+    g_x = torch.empty_like(x) if want_gx else None
+    _check(L.zest_mlp_train_bwd(C.byref(desc), _ptr_table(keep), _ptr(x), M, _ptr(saved), _ptr(out), _ptr(g_out),
+                                _ptr(work), _ptr(g_x), _ptr_table(grads), _stream(x)), "zest_mlp_train_bwd")
+    return g_x, grads
 
 
 # ----------------------------------------------------------------------------------- MLP

@@ -21,6 +21,9 @@ constexpr int kSavedPerSample = 8 * W + W + W + HW;                 // 2688
 constexpr int kWorkPerSample = 2 * W /*act ping-pong*/ + 4 * W /*d_a, d_b, act_re, dm*/ + W /*d_feat*/ +
                                HW /*d_hv*/ + 16 /*head pre / d*/ + 1 /*ones*/;
 
+constexpr int kSplitRows = 2048;                       // rows of M per weight-gradient partial product
+constexpr size_t kPartialFloats = (size_t)64 * 256 * 320;   // split-K partials: up to 64 x [256 x 319]
+
 struct Shape {
     int P, F, V, C_in, C_out, head, v2, mod, n_extra;
 };
@@ -60,18 +63,67 @@ bool gemm_dx(rocblas_handle h, int M, int N, int K, const float *dY, int ldy, co
     return rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_none, K, M, N, &one, Wt, ldw, dY, ldy,
                          &beta, dX, ldx) == rocblas_status_success;
 }
-// dWt[N,K] (ldw) = dY[M,N]^T (ldy) . X[M,K] (ldx)
-bool gemm_dw(rocblas_handle h, int M, int N, int K, const float *dY, int ldy, const float *X, int ldx,
-             float *dWt, int ldw) {
+// out[n] = sum_m A[m, n]  for n < N (N <= 256), A row-major with leading dimension lda.
+// One thread per column, 256 rows per block, one float atomic per column and block.
+__global__ void colsum_kernel(const float *__restrict__ A, int M, int N, int lda, float *__restrict__ out) {
+    const int n = threadIdx.x;
+    if (n >= N) return;
+    const int m0 = blockIdx.x * 256, m1 = min(m0 + 256, M);
+    float acc = 0.f;
+    for (int m = m0; m < m1; m++) acc += A[(size_t)m * lda + n];
+    atomicAdd(out + n, acc);
+}
+__global__ void zero_kernel(float *__restrict__ p, int n) {
+    if ((int)threadIdx.x < n) p[threadIdx.x] = 0.f;
+}
+// dW[n, k] (ldw) = sum_b partial[b][n][k]
+__global__ void reduce_partials_kernel(const float *__restrict__ part, int nb, int N, int K, float *__restrict__ dW,
+                                       int ldw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * K) return;
+    float acc = 0.f;
+    for (int b = 0; b < nb; b++) acc += part[(size_t)b * N * K + i];
+    dW[(size_t)(i / K) * ldw + (i % K)] = acc;
+}
+
+struct Ctx {
+    rocblas_handle h;
+    hipStream_t st;
+    float *partials;        // kPartialFloats of scratch for the split weight-gradient products
+};
+
+// dWt[N,K] (ldw) = dY[M,N]^T (ldy) . X[M,K] (ldx).  The reduction runs over M = rays x samples
+// (131 072 at the headline shape) into a 256 x 256 output, so it is split into kSplitRows-row
+// partial products (strided-batched sgemm: enough workgroups to fill the chip) and a reduce.
+bool gemm_dw(const Ctx &c, int M, int N, int K, const float *dY, int ldy, const float *X, int ldx, float *dWt,
+             int ldw) {
     const float one = 1.0f, zero = 0.0f;
-    return rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_transpose, K, N, M, &one, X, ldx, dY, ldy,
-                         &zero, dWt, ldw) == rocblas_status_success;
+    const int nb = M / kSplitRows, rem = M % kSplitRows;
+    if (nb == 0 || (size_t)(nb + 1) * N * K > kPartialFloats)
+        return rocblas_sgemm(c.h, rocblas_operation_none, rocblas_operation_transpose, K, N, M, &one, X, ldx, dY,
+                             ldy, &zero, dWt, ldw) == rocblas_status_success;
+    if (rocblas_sgemm_strided_batched(c.h, rocblas_operation_none, rocblas_operation_transpose, K, N, kSplitRows,
+                                      &one, X, ldx, (rocblas_stride)kSplitRows * ldx, dY, ldy,
+                                      (rocblas_stride)kSplitRows * ldy, &zero, c.partials, K,
+                                      (rocblas_stride)N * K, nb) != rocblas_status_success)
+        return false;
+    int np = nb;
+    if (rem) {
+        if (rocblas_sgemm(c.h, rocblas_operation_none, rocblas_operation_transpose, K, N, rem, &one,
+                          X + (size_t)nb * kSplitRows * ldx, ldx, dY + (size_t)nb * kSplitRows * ldy, ldy, &zero,
+                          c.partials + (size_t)nb * N * K, K) != rocblas_status_success)
+            return false;
+        np++;
+    }
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((N * K + 255) / 256), dim3(256), 0, c.st, c.partials, np, N, K,
+                       dWt, ldw);
+    return true;
 }
 // db[N] = column sums of dY[M,N] (ldy)
-bool col_sums(rocblas_handle h, int M, int N, const float *dY, int ldy, const float *ones, float *db) {
-    const float one = 1.0f, zero = 0.0f;
-    return rocblas_sgemv(h, rocblas_operation_none, N, M, &one, dY, ldy, ones, 1, &zero, db, 1) ==
-           rocblas_status_success;
+bool col_sums(const Ctx &c, int M, int N, const float *dY, int ldy, float *db) {
+    hipLaunchKernelGGL(zero_kernel, dim3(1), dim3(256), 0, c.st, db, N);
+    hipLaunchKernelGGL(colsum_kernel, dim3((M + 255) / 256), dim3(256), 0, c.st, dY, M, N, ldy, db);
+    return true;
 }
 
 // pre = y + b (in place);  act = relu(mod(pre, m))          [n columns per row]
@@ -164,7 +216,7 @@ extern "C" size_t zest_mlp_train_saved_floats(const zest_mlp_desc *desc, int M) 
     return desc && M > 0 ? (size_t)M * kSavedPerSample : 0;
 }
 extern "C" size_t zest_mlp_train_workspace_floats(const zest_mlp_desc *desc, int M) {
-    return desc && M > 0 ? (size_t)M * kWorkPerSample : 0;
+    return desc && M > 0 ? (size_t)M * kWorkPerSample + kPartialFloats : 0;
 }
 
 #define RB(x)                                                       \
@@ -269,10 +321,10 @@ extern "C" int zest_mlp_train_bwd(const zest_mlp_desc *desc, const float *const 
     for (int l = 0; l < 8; l++) pre[l] = saved + (size_t)l * MW;
     const float *mbuf = s.mod ? saved + 8 * MW : nullptr, *featl = saved + 9 * MW, *hvpre = saved + 10 * MW;
     float *da = workspace + 2 * MW, *db_ = workspace + 3 * MW, *act = workspace + 4 * MW, *dm = workspace + 5 * MW;
-    float *dfeat = workspace + 6 * MW, *dhv = workspace + 7 * MW, *dhp = dhv + MH, *ones = dhp + (long long)M * 16;
+    float *dfeat = workspace + 6 * MW, *dhv = workspace + 7 * MW, *dhp = dhv + MH;
+    const Ctx cx{h, st, workspace + (size_t)M * kWorkPerSample};
     const float *xp = x, *xf = x + s.P, *xv = x + s.P + s.F;
     float *gxp = g_x, *gxf = g_x ? g_x + s.P : nullptr;
-    EW(fill_kernel, (long long)M, ones, (long long)M, 1.f);
     if (s.mod) EW(fill_kernel, MW, dm, MW, 0.f);
     if (g_x) EW(fill_kernel, (long long)M * s.C_in, g_x, (long long)M * s.C_in, 0.f);
 
@@ -280,31 +332,31 @@ extern "C" int zest_mlp_train_bwd(const zest_mlp_desc *desc, const float *const 
     EW(heads_bwd_kernel, (long long)M * 16, g_out, out, M, s.C_out, s.head, s.v2, dhp);
     // rgb_linear on hv = relu(hvpre)
     EW(react_kernel, MH, hvpre, (const float *)nullptr, act, MH, 0);
-    RB(gemm_dw(h, M, 3, HW, dhp, 16, act, HW, g.w[ZEST_P_RGB], HW));
-    RB(col_sums(h, M, 3, dhp, 16, ones, g.b[ZEST_P_RGB]));
+    RB(gemm_dw(cx, M, 3, HW, dhp, 16, act, HW, g.w[ZEST_P_RGB], HW));
+    RB(col_sums(cx, M, 3, dhp, 16, g.b[ZEST_P_RGB]));
     RB(gemm_dx(h, M, 3, HW, dhp, 16, p.w[ZEST_P_RGB], HW, dhv, HW, 0.f));
     EW(act_bwd_kernel, MH, dhv, hvpre, (const float *)nullptr, (float *)nullptr, MH, 0);
     // views_linears.0 on [feature | views]
-    RB(gemm_dw(h, M, HW, W, dhv, HW, featl, W, g.w[ZEST_P_VIEWS], W + s.V));
-    RB(gemm_dw(h, M, HW, s.V, dhv, HW, xv, s.C_in, g.w[ZEST_P_VIEWS] + W, W + s.V));
-    RB(col_sums(h, M, HW, dhv, HW, ones, g.b[ZEST_P_VIEWS]));
+    RB(gemm_dw(cx, M, HW, W, dhv, HW, featl, W, g.w[ZEST_P_VIEWS], W + s.V));
+    RB(gemm_dw(cx, M, HW, s.V, dhv, HW, xv, s.C_in, g.w[ZEST_P_VIEWS] + W, W + s.V));
+    RB(col_sums(cx, M, HW, dhv, HW, g.b[ZEST_P_VIEWS]));
     RB(gemm_dx(h, M, HW, W, dhv, HW, p.w[ZEST_P_VIEWS], W + s.V, dfeat, W, 0.f));
     // trunk output h7 = relu(mod(pre7, m)): feature_linear, alpha and the extra heads read it
     EW(react_kernel, MW, pre[7], mbuf, act, MW, s.v2);
-    RB(gemm_dw(h, M, W, W, dfeat, W, act, W, g.w[ZEST_P_FEATURE], W));
-    RB(col_sums(h, M, W, dfeat, W, ones, g.b[ZEST_P_FEATURE]));
+    RB(gemm_dw(cx, M, W, W, dfeat, W, act, W, g.w[ZEST_P_FEATURE], W));
+    RB(col_sums(cx, M, W, dfeat, W, g.b[ZEST_P_FEATURE]));
     RB(gemm_dx(h, M, W, W, dfeat, W, p.w[ZEST_P_FEATURE], W, da, W, 0.f));
-    RB(gemm_dw(h, M, 1, W, dhp + 3, 16, act, W, g.w[ZEST_P_ALPHA], W));
-    RB(col_sums(h, M, 1, dhp + 3, 16, ones, g.b[ZEST_P_ALPHA]));
+    RB(gemm_dw(cx, M, 1, W, dhp + 3, 16, act, W, g.w[ZEST_P_ALPHA], W));
+    RB(col_sums(cx, M, 1, dhp + 3, 16, g.b[ZEST_P_ALPHA]));
     RB(gemm_dx(h, M, 1, W, dhp + 3, 16, p.w[ZEST_P_ALPHA], W, da, W, 1.f));
     if (s.head != ZEST_HEAD_NONE) {
         const int n0 = s.head == ZEST_HEAD_BLEND ? 1 : 6;
-        RB(gemm_dw(h, M, n0, W, dhp + 4, 16, act, W, g.w[ZEST_P_HEAD0], W));
-        RB(col_sums(h, M, n0, dhp + 4, 16, ones, g.b[ZEST_P_HEAD0]));
+        RB(gemm_dw(cx, M, n0, W, dhp + 4, 16, act, W, g.w[ZEST_P_HEAD0], W));
+        RB(col_sums(cx, M, n0, dhp + 4, 16, g.b[ZEST_P_HEAD0]));
         RB(gemm_dx(h, M, n0, W, dhp + 4, 16, p.w[ZEST_P_HEAD0], W, da, W, 1.f));
         if (s.head == ZEST_HEAD_DYNAMIC) {
-            RB(gemm_dw(h, M, 2, W, dhp + 10, 16, act, W, g.w[ZEST_P_HEAD1], W));
-            RB(col_sums(h, M, 2, dhp + 10, 16, ones, g.b[ZEST_P_HEAD1]));
+            RB(gemm_dw(cx, M, 2, W, dhp + 10, 16, act, W, g.w[ZEST_P_HEAD1], W));
+            RB(col_sums(cx, M, 2, dhp + 10, 16, g.b[ZEST_P_HEAD1]));
             RB(gemm_dx(h, M, 2, W, dhp + 10, 16, p.w[ZEST_P_HEAD1], W, da, W, 1.f));
         }
     }
@@ -312,28 +364,28 @@ extern "C" int zest_mlp_train_bwd(const zest_mlp_desc *desc, const float *const 
     float *dcur = da, *dnxt = db_;
     for (int l = 7; l >= 0; l--) {
         EW(act_bwd_kernel, MW, dcur, pre[l], mbuf, dm, MW, s.v2);           // dcur = dL/dpre_l
-        RB(col_sums(h, M, W, dcur, W, ones, g.b[l]));
+        RB(col_sums(cx, M, W, dcur, W, g.b[l]));
         if (l == 0) {
-            RB(gemm_dw(h, M, W, s.P, dcur, W, xp, s.C_in, g.w[0], s.P));
+            RB(gemm_dw(cx, M, W, s.P, dcur, W, xp, s.C_in, g.w[0], s.P));
             if (g_x) RB(gemm_dx(h, M, W, s.P, dcur, W, p.w[0], s.P, gxp, s.C_in, 1.f));
             break;
         }
         EW(react_kernel, MW, pre[l - 1], mbuf, act, MW, s.v2);              // input of layer l
         if (l == 5) {
-            RB(gemm_dw(h, M, W, s.P, dcur, W, xp, s.C_in, g.w[5], W + s.P));
-            RB(gemm_dw(h, M, W, W, dcur, W, act, W, g.w[5] + s.P, W + s.P));
+            RB(gemm_dw(cx, M, W, s.P, dcur, W, xp, s.C_in, g.w[5], W + s.P));
+            RB(gemm_dw(cx, M, W, W, dcur, W, act, W, g.w[5] + s.P, W + s.P));
             if (g_x) RB(gemm_dx(h, M, W, s.P, dcur, W, p.w[5], W + s.P, gxp, s.C_in, 1.f));
             RB(gemm_dx(h, M, W, W, dcur, W, p.w[5] + s.P, W + s.P, dnxt, W, 0.f));
         } else {
-            RB(gemm_dw(h, M, W, W, dcur, W, act, W, g.w[l], W));
+            RB(gemm_dw(cx, M, W, W, dcur, W, act, W, g.w[l], W));
             RB(gemm_dx(h, M, W, W, dcur, W, p.w[l], W, dnxt, W, 0.f));
         }
         float *t = dcur;
         dcur = dnxt, dnxt = t;
     }
     if (s.mod) {        // m = pts_bias(feats)
-        RB(gemm_dw(h, M, W, s.F, dm, W, xf, s.C_in, g.w[ZEST_P_PTS_BIAS], s.F));
-        RB(col_sums(h, M, W, dm, W, ones, g.b[ZEST_P_PTS_BIAS]));
+        RB(gemm_dw(cx, M, W, s.F, dm, W, xf, s.C_in, g.w[ZEST_P_PTS_BIAS], s.F));
+        RB(col_sums(cx, M, W, dm, W, g.b[ZEST_P_PTS_BIAS]));
         if (g_x) RB(gemm_dx(h, M, W, s.F, dm, W, p.w[ZEST_P_PTS_BIAS], s.F, gxf, s.C_in, 1.f));
     }
     ZEST_RETURN_LAUNCH("zest_mlp_train_bwd");

@@ -33,6 +33,7 @@ for p in (os.path.join(ROOT, "zest-nerf_amd"), ROOT):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+IMAGE_PIXELS = 288 * 512          # the NSFF evaluation image (configs/*.txt), 144 chunks of 1024 rays
 PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
 
 WORKLOADS = {
@@ -157,6 +158,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="nsff_static_1024x128", choices=list(WORKLOADS))
     ap.add_argument("--rays", type=int, default=None, help="rays per GPU (default: the workload's)")
+    ap.add_argument("--gather", default="image", choices=["image", "step"],
+                    help="N>1: all-gather the rendered maps once per image (default) or per call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     a = ap.parse_args()
@@ -169,9 +172,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     if a.gpus != world and rank == 0:
         print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (a.gpus, world), file=sys.stderr)
@@ -180,15 +184,32 @@ def main():
     zest_hip.lib()
     d = build_workload(a.workload, 1234 + rank, dev, a.rays)
     import zest_parallel
+    force = os.environ.get("ZEST_FORCE_COLLECTIVE") == "1" and dist is not None     # 1-rank rehearsal
+    # Multi-GPU: rank g renders its own ray blocks; the packed per-ray maps reach every
+    # rank by ONE RCCL all-gather, either per rendering call (--gather step) or, as the reference's
+    # whole-image loops allow (networks.py:697-704 concatenates chunks per image), once per image
+    # of IMAGE_PIXELS rays (--gather image, default): every rank keeps its chunks and pushes them
+    # in one message, so the latency-bound collective is paid once per image, not per chunk.
+    per_image = max(1, IMAGE_PIXELS // max(1, world * d.R))
+    chunks = []
+
+    def flush():
+        if chunks:
+            local = chunks[0] if len(chunks) == 1 else torch.cat(chunks, 0)
+            zest_parallel.gather_maps(local, world * local.shape[0], force=force)
+            chunks.clear()
 
     def step():
         ret = render_step(d)
-        if world > 1:       # ONE all-gather of the packed per-ray maps over RCCL/xGMI
-            return zest_parallel.gather_maps(ret["zest_packed_maps"], world * d.R)
+        if world > 1 or force:
+            chunks.append(ret["zest_packed_maps"])
+            if a.gather == "step" or len(chunks) >= per_image:
+                flush()
         return ret
 
     def fence():
-        if world > 1:
+        flush()                     # rays rendered in the timed region are gathered inside it
+        if world > 1 or force:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -212,7 +233,7 @@ def main():
         torch.cuda.synchronize()
         k_ms = float(np.mean([x.elapsed_time(y) for x, y in evs]))
     tmax = torch.tensor([el], device=dev, dtype=torch.float64)
-    if world > 1:
+    if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     el = float(tmax.item())
     if rank == 0:
@@ -225,7 +246,10 @@ def main():
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": a.workload, "rays_per_gpu": d.R, "samples_per_ray": d.S,
                        "note": d.cfg["note"], "path": "renderer.rendering -> zest_render_fused_fwd",
-                       "collective": "all_gather(rendered pixels)" if world > 1 else "none"},
+                       "collective": ("none" if world == 1 else "all_gather(packed per-ray maps) per rendering call"
+                                      if a.gather == "step" else
+                                      "all_gather(packed per-ray maps) once per %d-ray image = every %d calls"
+                                      % (IMAGE_PIXELS, per_image))},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(a.workload),
                          "kernel": "fused_blocks_kernel (+ fused_combine_kernel, ~3% of the bracket)",
@@ -237,7 +261,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(d, a.cpu_budget)
         print(json.dumps(out))
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -73,6 +73,42 @@ def test_shard_gather_matches_single_process(R):
         assert np.array_equal(full, want), "rank %d" % rank      # same ops per ray: bit-exact
 
 
+def _grad_worker(rank, world, port, out_q):
+    for p in (os.path.join(ROOT, "zest-nerf_amd"), ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import zest_parallel as zp
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in ((256, 63), (256,), (3, 128), (1,))]
+    for i, p in enumerate(params):
+        p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+    params.append(torch.nn.Parameter(torch.zeros(4)))            # no gradient: skipped
+    zp.allreduce_grads(params, bucket_bytes=40000)               # forces several buckets
+    out_q.put((rank, [float(p.grad.flatten()[0]) for p in params[:4]]))
+    # async gather returns a work handle that must be waited for
+    t, work = zp.gather_maps(torch.full((3, 2), float(rank)), 6, async_op=True)
+    work.wait()
+    assert t.tolist() == [[0.0, 0.0]] * 3 + [[1.0, 1.0]] * 3
+    dist.destroy_process_group()
+
+
+def test_allreduce_grads_averages_over_ranks():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, g in got:
+        assert g == [1.5 * (i + 1) for i in range(4)]             # mean of (1, 2) * (i + 1)
+
+
 def test_shard_bounds_cover_all_rays():
     import zest_parallel as zp
     for R in (0, 1, 7, 8, 1024, 1025):

@@ -32,9 +32,11 @@ rec_bytes = d.R * ((d.S + 31) // 32) * 80
 st = ws[rec_bytes:].view(torch.int64).cpu().numpy().reshape(-1, 8)
 st = st[st[:, 7] > 0]
 tot, enc, eng, comp, wait, issue, real, n = [st[:, i].astype(np.float64) for i in range(8)]
+vm, n = (st[:, 7] >> 16).astype(np.float64), (st[:, 7] & 0xFFFF).astype(np.float64)
 clk = tot.mean() / (real.mean() / 100e6) / 1e9
 print("%s: %d waves, passes/wave %.1f, wave lifetime %.0f cycles = %.1f us at %.2f GHz"
       % (wl, len(st), n.mean(), tot.mean(), real.mean() / 100, clk))
-for name, v in (("encode", enc), ("engine", eng), ("  of which chunk wait+barrier", wait),
+for name, v in (("encode", enc), ("engine", eng), ("  of which chunk wait+sync", wait),
+                ("    of which own-DMA (vmcnt) wait", vm),
                 ("  of which DMA issue", issue), ("composite+store", comp)):
     print("  %-32s %9.0f cycles  %5.1f %%" % (name, v.mean(), 100 * v.mean() / tot.mean()))

@@ -13,11 +13,13 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libzest_hip.so")
 SOURCES = ["capi.hip", "composite.hip", "composite_bwd.hip", "encode.hip", "rays.hip", "mlp_plan.hip", "mlp.hip", "mlp_bf16.hip", "mlp_train.hip",
-           "fused.hip", "fused_s0.hip", "fused_s2.hip", "fused_s3.hip", "fused_s0d0.hip",
-           "fused_s3d2.hip", "fused_s2d2.hip", "fused_s2d0.hip", "fused_s3d0.hip"]
+           "fused.hip", "fused_s0.hip", "fused_s2.hip", "fused_s4.hip", "fused_s0d0.hip",
+           "fused_s4d2.hip", "fused_s2d2.hip", "fused_s2d0.hip", "fused_s4d0.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
-         "-Wno-inline-asm"]     # the LDS-DMA asm declares the reserved register m0 clobbered on purpose
+         "-Wno-inline-asm",     # the LDS-DMA asm declares the reserved register m0 clobbered on purpose
+         # the network is one fully unrolled body per kernel: keep `#pragma unroll` honoured
+         "-mllvm", "-pragma-unroll-threshold=1000000"]
 
 
 def _deps():

@@ -1,11 +1,12 @@
 // Fused inference renderer: per-sample work never leaves the chip.
 //
-// Rays are cut into blocks of 32 samples.  For its blocks a wave's lanes build the MLP
-// operands in registers (sin/cos on the two lane halves of one sincos, volume channels and
-// source views split between the halves), the bf16 engine (mlp_engine.cuh) runs the whole
-// network on them with the weights streamed through an LDS ring shared by the workgroup, and
-// the raw colour/density land back on the lanes, where a 32-lane shuffle scan composites the
-// block.  Per block 80 B leave the chip; a second tiny kernel chains the blocks of each ray
+// Rays are cut into blocks of 32 samples = two MFMA column blocks of 16.  For its blocks a
+// wave's lanes build the MLP operands in registers (lane l: sample column l & 15 of each
+// column block, as group g = l >> 4: sin/cos and the band of a pair, volume channel quads and
+// source views are split over the four groups), the bf16 engine (mlp_engine.cuh) runs the
+// whole network on them with the weights streamed through an LDS ring shared by the workgroup,
+// and the raw colour/density land on lanes 0-15 of each column block; one v_permlane16_swap
+// per value lines the 32 samples up on lanes 0-31, where a shuffle scan composites the block.  Per block 80 B leave the chip; a second tiny kernel chains the blocks of each ray
 // into the per-ray maps (64 B per ray).
 //
 // Replaces rendering(..., val=True) of the reference (renderer.py:579-626 with the early
@@ -48,34 +49,35 @@ __device__ __forceinline__ bf16x8 pack_tile(const float (&v)[8]) {
     return *reinterpret_cast<bf16x8 *>(&a);
 }
 
-// Positional-encoding operand for C coordinates and L bands in plan slot order
-// (mlp_plan.hip pe_map_acc): slot q < L*C holds sin (half 0) / cos (half 1) of
-// 2^(q/C) * x[q%C]; then the raw coordinates two per slot; zero padding after that.
+// Positional-encoding operand for C coordinates and L (even) bands in plan position order
+// (mlp_plan.hip pe_map_acc): element e of k-tile kt is m = 8 kt + e; m < (L/2) C is
+// sin (g even) / cos (g odd) of 2^(2 (m / C) + (g >> 1)) x[m % C]; m = (L/2) C is the raw
+// coordinate x[g]; zero after that.
 // The engine rounds operands to bf16 (8 significant bits), so the hardware sine is used:
 // v_sin_f32 takes revolutions, cos is sin shifted by a quarter revolution, and the range
 // reduction is one v_fract.  Its absolute error (~1e-6) plus the rounding of arg/(2 pi)
 // (3e-5 rad at 2^9 x) is 1/50 of a bf16 ulp; the fp32 per-op path (encode.hip) keeps the
 // accurate sincos.
-template <int C, int L, int NT>
-__device__ __forceinline__ void encode_pe_operand(const float (&x)[4], int half, OpArr<NT> &op) {
-    static_assert(L * C + (C + 1) / 2 <= NT * 8, "slot layout");
-    const float quarter = half ? 0.25f : 0.0f;
+template <int C, int L, int NK>
+__device__ __forceinline__ void encode_pe_operand(const float (&x)[4], int grp, OpArr<NK> &op) {
+    static_assert((L / 2) * C + 1 <= NK * 8 && L % 2 == 0, "position layout");
+    const float quarter = (grp & 1) ? 0.25f : 0.0f;
+    const float gscale = (grp & 2) ? 2.0f * 0.15915494309189535f : 0.15915494309189535f;
     float rev[C];
 #pragma unroll
-    for (int c = 0; c < C; c++) rev[c] = x[c] * 0.15915494309189535f;      // revolutions at band 0
+    for (int c = 0; c < C; c++) rev[c] = x[c] * gscale;      // revolutions at the group's band of pair 0
+    const float raw = grp == 0 ? x[0] : (grp == 1 ? x[1] : (grp == 2 ? x[2] : (C > 3 ? x[3] : 0.0f)));
 #pragma unroll
-    for (int t = 0; t < NT; t++) {
+    for (int t = 0; t < NK; t++) {
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-            const int q = 8 * t + e;
-            if (q < L * C) {
-                const float r = fmaf(rev[q % C], (float)(1 << (q / C)), quarter);
+            const int m = 8 * t + e;
+            if (m < (L / 2) * C) {
+                const float r = fmaf(rev[m % C], (float)(1 << (2 * (m / C))), quarter);
                 v[e] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(r));
-            } else if (q < L * C + (C + 1) / 2) {
-                const int p = q - L * C;
-                const float lo = x[2 * p], hi = (2 * p + 1 < C) ? x[2 * p + 1] : 0.0f;
-                v[e] = half ? hi : lo;
+            } else if (m == (L / 2) * C) {
+                v[e] = raw;
             } else {
                 v[e] = 0.0f;
             }
@@ -84,20 +86,36 @@ __device__ __forceinline__ void encode_pe_operand(const float (&x)[4], int half,
     }
 }
 
-// Feature operand (mlp_plan.hip feat_map_acc): slots 0-3 = volume channels 4*half..+3,
-// slots 4+4p+c = channel c of source view 2p+half.
-template <int NT>
+// Feature operand (mlp_plan.hip feat_map_acc): a lane's eight values of k-tile kt are the
+// 4-channel quads q = 8 kt + 2 g and q + 1; quad 0 / 2 = volume channels 0-3 / 4-7, quad 1 / 3 =
+// source view 0 / 1, quad q >= 4 = source view q - 2.
+template <int NK>
 __device__ __forceinline__ void encode_feat_operand(const FusedNet &n, const float *cams_lds,
                                                     const float (&ndc)[4], const float (&pw)[3],
-                                                    int half, bool valid, OpArr<NT> &op) {
-    float v[NT * 8];
+                                                    int grp, bool valid, OpArr<NK> &op) {
+    float v[NK * 8];
 #pragma unroll
-    for (int i = 0; i < NT * 8; i++) v[i] = 0.0f;
+    for (int i = 0; i < NK * 8; i++) v[i] = 0.0f;
+    auto view_tap = [&](int view, float *dst) {       // view >= V: clamped address, result dropped
+        const int vc = view < n.V ? view : n.V - 1;
+        ZestCam cam;
+        const float *cl = cams_lds + vc * kCamStride;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) cam.r[i][j] = cl[4 * i + j];
+#pragma unroll
+            for (int j = 0; j < 3; j++) cam.k[i][j] = cl[12 + 3 * i + j];
+        }
+        const float4 o = zest_color_tap(n.imgs + (size_t)vc * n.H * n.W, n.H, n.W, cam, pw[0], pw[1], pw[2]);
+        const bool on = view < n.V;
+        dst[0] = on ? o.x : 0.f, dst[1] = on ? o.y : 0.f, dst[2] = on ? o.z : 0.f, dst[3] = on ? o.w : 0.f;
+    };
     if (valid) {
-        // Trilinear lookup of this half's four channels.  Branch-free: out-of-volume corners
-        // read a clamped address with weight 0, so all eight 16-byte loads are in flight
-        // together instead of one divergent branch (and one memory round trip) per corner.
-        {
+        if (grp < 2) {
+            // Trilinear lookup of this group's four channels.  Branch-free: out-of-volume corners
+            // read a clamped address with weight 0, so all eight 16-byte loads are in flight
+            // together instead of one divergent branch (and one memory round trip) per corner.
             float fx = zest_unnorm(ndc[0], n.Wv), fy = zest_unnorm(ndc[1], n.Hv), fz = zest_unnorm(ndc[2], n.D);
             fx = fminf(fmaxf(fx, -2.0f), (float)n.Wv + 1.0f);
             fy = fminf(fmaxf(fy, -2.0f), (float)n.Hv + 1.0f);
@@ -116,36 +134,25 @@ __device__ __forceinline__ void encode_feat_operand(const FusedNet &n, const flo
                 const int xc = min(max(xi, 0), n.Wv - 1), yc = min(max(yi, 0), n.Hv - 1),
                           zc = min(max(zi, 0), n.D - 1);
                 wgt[c] = ok ? (dx ? tx : 1.0f - tx) * (dy ? ty : 1.0f - ty) * (dz ? tz : 1.0f - tz) : 0.0f;
-                tap[c] = n.vol[2 * (((size_t)zc * n.Hv + yc) * n.Wv + xc) + half];
+                tap[c] = n.vol[2 * (((size_t)zc * n.Hv + yc) * n.Wv + xc) + grp];
             }
 #pragma unroll
             for (int c = 0; c < 8; c++) {
                 v[0] = fmaf(wgt[c], tap[c].x, v[0]), v[1] = fmaf(wgt[c], tap[c].y, v[1]);
                 v[2] = fmaf(wgt[c], tap[c].z, v[2]), v[3] = fmaf(wgt[c], tap[c].w, v[3]);
             }
+        } else {
+            view_tap(2 * grp - 2, v);                      // quads 4, 6 = views 2, 4
         }
-        // source views 2p+half: the view index beyond V is clamped and its result discarded
+        view_tap(grp < 2 ? grp : 2 * grp - 1, v + 4);      // quads 1, 3, 5, 7 = views 0, 1, 3, 5
 #pragma unroll
-        for (int p = 0; p < (NT * 8 - 4) / 4; p++) {
-            const int view = 2 * p + half;
-            const int vc = view < n.V ? view : n.V - 1;
-            ZestCam cam;
-            const float *cl = cams_lds + vc * kCamStride;
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) cam.r[i][j] = cl[4 * i + j];
-#pragma unroll
-                for (int j = 0; j < 3; j++) cam.k[i][j] = cl[12 + 3 * i + j];
-            }
-            const float4 o = zest_color_tap(n.imgs + (size_t)vc * n.H * n.W, n.H, n.W, cam, pw[0], pw[1], pw[2]);
-            const bool on = view < n.V;
-            v[4 + 4 * p] = on ? o.x : 0.f, v[5 + 4 * p] = on ? o.y : 0.f;
-            v[6 + 4 * p] = on ? o.z : 0.f, v[7 + 4 * p] = on ? o.w : 0.f;
+        for (int t = 1; t < NK; t++) {                     // quads 8 t + 2 g (+ 1) = views 8 t + 2 g - 2 (- 1)
+            view_tap(8 * t + 2 * grp - 2, v + 8 * t);
+            view_tap(8 * t + 2 * grp - 1, v + 8 * t + 4);
         }
     }
 #pragma unroll
-    for (int t = 0; t < NT; t++) {
+    for (int t = 0; t < NK; t++) {
         float w8[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) w8[e] = v[8 * t + e];
@@ -182,6 +189,7 @@ struct BlockSamples {              // what a lane keeps about its sample across 
 // on its two blocks while all four waves share the weight stream through the LDS ring.  Each
 // block is composited on its own with entry transmittance 1 and leaves a record (exit
 // transmittance + weighted sums); combine_kernel chains the records of a ray.
+// NT_FEAT_*: stream units of the feature operand per row block (2 x its k-tiles; 0 = no features)
 template <int NT_FEAT_S, bool DYN, int NT_FEAT_D>
 #ifndef ZEST_FUSED_WG_PER_CU
 #define ZEST_FUSED_WG_PER_CU 1
@@ -193,29 +201,38 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
     using Ring = RingTiles<kFusedWaves, UNITS_S, UNITS_D>;
     // LDS: weight ring | cameras of both nets | per-lane (z, dist) of the pass's samples
     __shared__ __attribute__((aligned(16))) char lds[kRingUnits * 1024 + 2 * kMaxViews * kCamStride * 4 +
-                                                     kFusedWaves * NB * 32 * 8];
+                                                     kFusedWaves * NB * 32 * 8 + 2 * kSlots * 4];
     float *cams_s = reinterpret_cast<float *>(lds + kRingUnits * 1024), *cams_d = cams_s + kMaxViews * kCamStride;
     float2 *zd_lds = reinterpret_cast<float2 *>(cams_d + kMaxViews * kCamStride);
     stage_cams(a.st, cams_s);
     if (DYN) stage_cams(a.dy, cams_d);
+#ifdef ZEST_RING_FLAGS
+    int *ring_flags = reinterpret_cast<int *>(zd_lds + kFusedWaves * NB * 32);
+    Ring::init_flags(ring_flags);
+#endif
     __syncthreads();
 
-    const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
+    const int lane = threadIdx.x & 63, col = lane & 15, grp = lane >> 4, c32 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const Ring tiles{lds, (gptr_u4)a.st.tiles, (gptr_u4)a.dy.tiles, lane, half, wave,
+    const Ring tiles{lds, (gptr_u4)a.st.tiles, (gptr_u4)a.dy.tiles, lane, grp, wave,
                      (unsigned)(wave * Ring::kPieces * 64 + lane) * 16u,
                      (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds +
-                         (unsigned)wave * Ring::kPieces * 1024u};
+                         (unsigned)wave * Ring::kPieces * 1024u
+#ifdef ZEST_RING_FLAGS
+                     , (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)ring_flags
+#endif
+    };
+    tiles.init_addr();
     tiles.prologue();
 
     const int n_blocks = a.R * a.bpr;
     const int n_pass = (n_blocks + kFusedWaves * NB - 1) / (kFusedWaves * NB);
-    // A lane's sample is re-read from global memory (L1/L2 hits) wherever it is needed instead
-    // of being held in registers across the network: the engine needs the registers more.
-    auto fetch = [&](int pass, int nb, BlockSamples &b, int &gidx, const float *&dir) {
-        const int g = (pass * kFusedWaves + wave) * NB + nb;
-        gidx = g < n_blocks ? g : -1;
-        const int r = g < n_blocks ? g / a.bpr : 0, s = (g % a.bpr) * 32 + col;
+    // A lane's samples (column block cb = 2 nb + h: sample 16 h + col of block nb) are re-read
+    // from global memory (L1/L2 hits) wherever they are needed instead of being held in
+    // registers across the network: the engine needs the registers more.
+    auto fetch = [&](int pass, int cb, BlockSamples &b, const float *&dir) {
+        const int g = (pass * kFusedWaves + wave) * NB + cb / 2;
+        const int r = g < n_blocks ? g / a.bpr : 0, s = (g % a.bpr) * 32 + 16 * (cb & 1) + col;
         b.valid = g < n_blocks && s < a.S;
         b.x[0] = b.x[1] = b.x[2] = 0.f, b.x[3] = a.frame_idx;
         b.pw[0] = b.pw[1] = b.pw[2] = 0.f, b.zz = 0.f, b.dist = 0.f;
@@ -230,6 +247,12 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
             b.dist = ((s + 1 < a.S) ? (zr[s + 1] - b.zz) : 1e10f) * dnorm;
         }
     };
+    // value of column block 2 nb on lanes 0-15 and of 2 nb + 1 on lanes 0-15 -> the block's 32
+    // samples on lanes 0-31 (v_permlane16_swap: row 1 of the first operand <-> row 0 of the second)
+    auto join = [](float lo, float hi) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+        return __uint_as_float(r[0]);
+    };
 #ifdef ZEST_STAMPS
     unsigned long long st_enc = 0, st_eng = 0, st_comp = 0, st_n = 0;
     const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
@@ -237,45 +260,46 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
 #else
 #define ZEST_STAMP(var) do {} while (0)
 #endif
+    constexpr int CB = 2 * NB;
     for (int pass = blockIdx.x; pass < n_pass; pass += gridDim.x) {
 #ifdef ZEST_STAMPS
         unsigned long long st_last = __builtin_amdgcn_s_memtime();
         st_n++;
 #endif
         int unit = 0;
-        f32x16 head_s[NB], rgb_s[NB], head_d[NB], rgb_d[NB];
+        f32x4 head_s[CB], rgb_s[CB], head_d[CB], rgb_d[CB];
         // direction operand of net `n`, built when the engine reaches the view layer
         auto views_of = [&](const FusedNet &n, const float *cams) {
-            return [&, cams](OpArr<2> (&views)[NB]) {
+            return [&, cams](OpArr<1> (&views)[CB]) {
 #pragma unroll
                 for (int nb = 0; nb < NB; nb++) {
                     const int g = (pass * kFusedWaves + wave) * NB + nb;
                     const float *dir = a.dir + 3 * (g < n_blocks ? g / a.bpr : 0);
                     float dv[4] = {0.f, 0.f, 0.f, 0.f};
                     zest_view_dir(dir, n.w2cs ? cams : nullptr, dv);
-                    encode_pe_operand<3, 4, 2>(dv, half, views[nb]);
+                    encode_pe_operand<3, 4, 1>(dv, grp, views[2 * nb]);
+                    views[2 * nb + 1] = views[2 * nb];         // one ray per block
                 }
             };
         };
         {
-            OpArr<4> pts_s[NB];
-            OpArr<NT_FEAT_S> feat_s[NB];
+            OpArr<2> pts_s[CB];
+            OpArr<NT_FEAT_S / 2> feat_s[CB];
 #pragma unroll
-            for (int nb = 0; nb < NB; nb++) {
+            for (int cb = 0; cb < CB; cb++) {
                 BlockSamples b;
-                int g;
                 const float *dir;
-                fetch(pass, nb, b, g, dir);
+                fetch(pass, cb, b, dir);
                 // compositing needs z and the sample spacing after the engine: park them in LDS so
                 // that phase issues no global load (a vmcnt wait there would drain the weight DMA)
-                if (half == 0) zd_lds[(wave * NB + nb) * 32 + col] = make_float2(b.zz, b.valid ? b.dist : -1.0f);
+                if (grp == 0) zd_lds[(wave * NB + cb / 2) * 32 + 16 * (cb & 1) + col] = make_float2(b.zz, b.valid ? b.dist : -1.0f);
 #ifdef ZEST_EXPERIMENT_NO_ENCODE        // timing experiment only
 #pragma unroll
-                for (int t = 0; t < 4; t++) pts_s[nb].t[t] = bf16x8{(short)lane, 1, 2, 3, 4, 5, 6, 7};
+                for (int t = 0; t < 2; t++) pts_s[cb].t[t] = bf16x8{(short)lane, 1, 2, 3, 4, 5, 6, 7};
 #else
-                encode_pe_operand<3, 10, 4>(b.x, half, pts_s[nb]);
+                encode_pe_operand<3, 10, 2>(b.x, grp, pts_s[cb]);
 #endif
-                if constexpr (MOD_S) encode_feat_operand<NT_FEAT_S>(a.st, cams_s, b.x, b.pw, half, b.valid, feat_s[nb]);
+                if constexpr (MOD_S) encode_feat_operand<NT_FEAT_S / 2>(a.st, cams_s, b.x, b.pw, grp, b.valid, feat_s[cb]);
             }
             ZEST_STAMP(st_enc);
             engine_forward<NB, 4, MOD_S, NT_FEAT_S>(tiles, unit, a.st.v2 != 0, pts_s, feat_s,
@@ -283,33 +307,34 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
             ZEST_STAMP(st_eng);
         }
         if (DYN) {
-            OpArr<6> pts_d[NB];
-            OpArr<NT_FEAT_D> feat_d[NB];
+            OpArr<3> pts_d[CB];
+            OpArr<NT_FEAT_D / 2> feat_d[CB];
 #pragma unroll
-            for (int nb = 0; nb < NB; nb++) {
+            for (int cb = 0; cb < CB; cb++) {
                 BlockSamples b;
-                int g;
                 const float *dir;
-                fetch(pass, nb, b, g, dir);
-                encode_pe_operand<4, 10, 6>(b.x, half, pts_d[nb]);
-                if constexpr (MOD_D) encode_feat_operand<NT_FEAT_D>(a.dy, cams_d, b.x, b.pw, half, b.valid, feat_d[nb]);
+                fetch(pass, cb, b, dir);
+                encode_pe_operand<4, 10, 3>(b.x, grp, pts_d[cb]);
+                if constexpr (MOD_D) encode_feat_operand<NT_FEAT_D / 2>(a.dy, cams_d, b.x, b.pw, grp, b.valid, feat_d[cb]);
             }
             ZEST_STAMP(st_enc);
             engine_forward<NB, 6, MOD_D, NT_FEAT_D>(tiles, unit, false, pts_d, feat_d,
                                                     views_of(a.dy, cams_d), head_d, rgb_d);
             ZEST_STAMP(st_eng);
         }
-        // ---- per-block compositing on lane half 0 (rgb tile rows 0-2, head tile rows 0,1)
+        // ---- per-block compositing on lanes 0-31 (sample = lane): rgb rows 0-2, head rows 0, 1
+        // sit in elements 0-2 / 0, 1 of lane group 0 of each column block
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) {
             BlockSamples b;
             const int g_ = (pass * kFusedWaves + wave) * NB + nb;
             const int gidx = g_ < n_blocks ? g_ : -1;
             {
-                const float2 zd = zd_lds[(wave * NB + nb) * 32 + col];
+                const float2 zd = zd_lds[(wave * NB + nb) * 32 + c32];
                 b.zz = zd.x, b.dist = fmaxf(zd.y, 0.0f), b.valid = zd.y >= 0.0f;
             }
-            float cr = rgb_s[nb][0], cg = rgb_s[nb][1], cb = rgb_s[nb][2], sg = head_s[nb][0];
+            float cr = join(rgb_s[2 * nb][0], rgb_s[2 * nb + 1][0]), cg = join(rgb_s[2 * nb][1], rgb_s[2 * nb + 1][1]),
+                  cb = join(rgb_s[2 * nb][2], rgb_s[2 * nb + 1][2]), sg = join(head_s[2 * nb][0], head_s[2 * nb + 1][0]);
             if (a.st.v2) {   // 'v2' nets activate inside the network; the compositor does it again
                 cr = zest_sigmoid(cr), cg = zest_sigmoid(cg), cb = zest_sigmoid(cb), sg = fmaxf(sg, 0.f);
             }
@@ -320,20 +345,22 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
             for (int i = 0; i < kPartialFloats; i++) rec[i] = 0.f;
             {
                 float tot;
-                const float w = al_s * lower_half_excl_prod(1.0f - al_s + 1e-10f, col, &tot);
+                const float w = al_s * lower_half_excl_prod(1.0f - al_s + 1e-10f, c32, &tot);
                 rec[0] = tot;
                 rec[1] = lower_half_sum(w * cr), rec[2] = lower_half_sum(w * cg), rec[3] = lower_half_sum(w * cb);
                 rec[4] = lower_half_sum(w * b.zz), rec[5] = lower_half_sum(w);
             }
             if (DYN) {
-                const float blend = zest_sigmoid(head_s[nb][1]);
-                const float er = zest_sigmoid(rgb_d[nb][0]), eg = zest_sigmoid(rgb_d[nb][1]),
-                            eb = zest_sigmoid(rgb_d[nb][2]);
-                const float a_fg = b.valid ? 1.0f - expf(-fmaxf(head_d[nb][0], 0.f) * b.dist) : 0.0f;
+                const float blend = zest_sigmoid(join(head_s[2 * nb][1], head_s[2 * nb + 1][1]));
+                const float er = zest_sigmoid(join(rgb_d[2 * nb][0], rgb_d[2 * nb + 1][0])),
+                            eg = zest_sigmoid(join(rgb_d[2 * nb][1], rgb_d[2 * nb + 1][1])),
+                            eb = zest_sigmoid(join(rgb_d[2 * nb][2], rgb_d[2 * nb + 1][2]));
+                const float sg_d = join(head_d[2 * nb][0], head_d[2 * nb + 1][0]);
+                const float a_fg = b.valid ? 1.0f - expf(-fmaxf(sg_d, 0.f) * b.dist) : 0.0f;
                 const float a_d = a_fg * blend, a_st = al_s * (1.0f - blend);
                 float tot_b, tot_f;
-                const float Tb = lower_half_excl_prod((1.0f - a_d) * (1.0f - a_st) + 1e-10f, col, &tot_b);
-                const float wf = a_fg * lower_half_excl_prod(1.0f - a_fg + 1e-10f, col, &tot_f);
+                const float Tb = lower_half_excl_prod((1.0f - a_d) * (1.0f - a_st) + 1e-10f, c32, &tot_b);
+                const float wf = a_fg * lower_half_excl_prod(1.0f - a_fg + 1e-10f, c32, &tot_f);
                 const float wd = Tb * a_d, ws = Tb * a_st;
                 rec[6] = tot_b;
                 rec[7] = lower_half_sum(wd * er + ws * cr), rec[8] = lower_half_sum(wd * eg + ws * cg);
@@ -351,13 +378,20 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
             }
         }
         ZEST_STAMP(st_comp);
+        tiles.next_pass();
     }
     tiles.drain();
+#ifdef ZEST_RING_FLAGS
+    if (tiles.poisoned && lane == 0) {
+        a.partials[0] = __builtin_nanf("");   // make a protocol failure visible
+    }
+#endif
 #ifdef ZEST_STAMPS
     if (a.stamps && lane == 0) {
         unsigned long long *o = a.stamps + (size_t)(blockIdx.x * kFusedWaves + wave) * 8;
         o[0] = __builtin_amdgcn_s_memtime() - st_t0, o[1] = st_enc, o[2] = st_eng, o[3] = st_comp;
-        o[4] = tiles.t_wait, o[5] = tiles.t_issue, o[6] = __builtin_amdgcn_s_memrealtime() - st_r0, o[7] = st_n;
+        o[4] = tiles.t_wait, o[5] = tiles.t_issue, o[6] = __builtin_amdgcn_s_memrealtime() - st_r0,
+        o[7] = st_n | (tiles.t_vm << 16);
     }
 #endif
 }
@@ -380,11 +414,11 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
     int fused_wg_per_cu_##tag();
 ZEST_FUSED_DECL(s0)
 ZEST_FUSED_DECL(s2)
-ZEST_FUSED_DECL(s3)
+ZEST_FUSED_DECL(s4)
 ZEST_FUSED_DECL(s0d0)
 ZEST_FUSED_DECL(s2d0)
-ZEST_FUSED_DECL(s3d0)
+ZEST_FUSED_DECL(s4d0)
 ZEST_FUSED_DECL(s2d2)
-ZEST_FUSED_DECL(s3d2)
+ZEST_FUSED_DECL(s4d2)
 
 }  // namespace zest

@@ -145,12 +145,12 @@ extern "C" int zest_render_fused_fwd(const float *ndc, const float *pts, const f
     switch (key) {
         ZEST_CASE(0, s0)
         ZEST_CASE(20, s2)
-        ZEST_CASE(30, s3)
+        ZEST_CASE(40, s4)
         ZEST_CASE(100, s0d0)
         ZEST_CASE(120, s2d0)
-        ZEST_CASE(130, s3d0)
+        ZEST_CASE(140, s4d0)
         ZEST_CASE(122, s2d2)
-        ZEST_CASE(132, s3d2)
+        ZEST_CASE(142, s4d2)
         default:
             zest_set_error("zest_render_fused_fwd: no fused variant for %d static / %d dynamic feature "
                            "tiles%s", nts, ntd, dyn ? "" : " (static only)");

@@ -5,25 +5,25 @@
 
 namespace zest {
 
-struct SlotMaps {            // feature index per slot and lane half, -1 = zero pad
-    short pts[48][2];
-    short feat[32][2];
-    short views[16][2];
+struct PosMaps {             // feature index per operand position (kt*32 + 8*grp + e), -1 = zero pad
+    short pts[96];
+    short feat[64];
+    short views[32];
 };
 
-template <int NT>
-__device__ __forceinline__ void load_operand(const float *__restrict__ xrow, bool valid, int half,
-                                             const short (*map)[2], OpArr<NT> &op) {
+// k-tiles of one column block's operand from its sample's input row
+template <int NK>
+__device__ __forceinline__ void load_operand(const float *__restrict__ xrow, bool valid, int grp,
+                                             const short *map, OpArr<NK> &op) {
 #pragma unroll
-    for (int t = 0; t < NT; t++) {
+    for (int t = 0; t < NK; t++) {
         unsigned w[4];
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) {
             float v[2];
 #pragma unroll
             for (int u = 0; u < 2; u++) {
-                const int s = 8 * t + 2 * jj + u;
-                const int idx = half ? map[s][1] : map[s][0];
+                const int idx = map[32 * t + 8 * grp + 2 * jj + u];
                 v[u] = (valid && idx >= 0) ? xrow[idx < 0 ? 0 : idx] : 0.0f;
             }
             w[jj] = pack_bf16(v[0], v[1]);
@@ -33,61 +33,63 @@ __device__ __forceinline__ void load_operand(const float *__restrict__ xrow, boo
     }
 }
 
+// A wave runs NB blocks of 32 rows = 2 NB column blocks of 16 (lane: column l & 15, group l >> 4).
 template <int NB, int NT_PTS, bool MOD, int NT_FEAT>
 __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void mlp_bf16_kernel(
-    SlotMaps maps, const uint4 *__restrict__ tiles, const float *__restrict__ x, int M, int P, int F, int C_in, int C_out, int head, int v2,
+    PosMaps maps, const uint4 *__restrict__ tiles, const float *__restrict__ x, int M, int P, int F, int C_in, int C_out, int head, int v2,
     float *__restrict__ out) {
+    constexpr int CB = 2 * NB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int col = lane & 31, half = lane >> 5;
+    const int col = lane & 15, grp = lane >> 4;
     const long long m_base = ((long long)blockIdx.x * 4 + wave) * (32 * NB);
     if (m_base >= M) return;                       // wave-uniform
-    OpArr<NT_PTS> pts[NB];
-    OpArr<NT_FEAT> feat[NB];
+    OpArr<NT_PTS / 2> pts[CB];
+    OpArr<NT_FEAT / 2> feat[CB];
 #pragma unroll
-    for (int nb = 0; nb < NB; nb++) {
-        const long long m = m_base + 32 * nb + col;
+    for (int cb = 0; cb < CB; cb++) {
+        const long long m = m_base + 16 * cb + col;
         const bool valid = m < M;
         const float *xrow = x + (size_t)(valid ? m : 0) * C_in;
-        load_operand<NT_PTS>(xrow, valid, half, maps.pts, pts[nb]);
-        if (MOD) load_operand<NT_FEAT>(xrow + P, valid, half, maps.feat, feat[nb]);
+        load_operand<NT_PTS / 2>(xrow, valid, grp, maps.pts, pts[cb]);
+        if (MOD) load_operand<NT_FEAT / 2>(xrow + P, valid, grp, maps.feat, feat[cb]);
     }
-    auto views_fn = [&](OpArr<2> (&views)[NB]) {
+    auto views_fn = [&](OpArr<1> (&views)[CB]) {
 #pragma unroll
-        for (int nb = 0; nb < NB; nb++) {
-            const long long m = m_base + 32 * nb + col;
+        for (int cb = 0; cb < CB; cb++) {
+            const long long m = m_base + 16 * cb + col;
             const bool valid = m < M;
-            load_operand<2>(x + (size_t)(valid ? m : 0) * C_in + P + F, valid, half, maps.views, views[nb]);
+            load_operand<1>(x + (size_t)(valid ? m : 0) * C_in + P + F, valid, grp, maps.views, views[cb]);
         }
     };
-    f32x16 headt[NB], rgbt[NB];
-    GlobalTiles gt{(gptr_u4)tiles, lane, half};
+    f32x4 headt[CB], rgbt[CB];
+    GlobalTiles gt{(gptr_u4)tiles, lane, grp};
     int unit = 0;
     engine_forward<NB, NT_PTS, MOD, NT_FEAT>(gt, unit, v2 != 0, pts, feat, views_fn, headt, rgbt);
 #pragma unroll
-    for (int nb = 0; nb < NB; nb++) {
-        const long long m = m_base + 32 * nb + col;
+    for (int cb = 0; cb < CB; cb++) {
+        const long long m = m_base + 16 * cb + col;
         if (m >= M) continue;
         float *o = out + (size_t)m * C_out;
-        // tile row r sits in lane half (r>>2)&1, register (r&3) + 4*(r>>3)
-        if (half == 0) {
-            o[0] = v2 ? zest_sigmoid(rgbt[nb][0]) : rgbt[nb][0];
-            o[1] = v2 ? zest_sigmoid(rgbt[nb][1]) : rgbt[nb][1];
-            o[2] = v2 ? zest_sigmoid(rgbt[nb][2]) : rgbt[nb][2];
-            o[3] = v2 ? fmaxf(headt[nb][0], 0.0f) : headt[nb][0];
-            if (head == ZEST_HEAD_BLEND) o[4] = zest_sigmoid(headt[nb][1]);
-            if (head == ZEST_HEAD_DYNAMIC) {
-                o[4] = tanhf(headt[nb][1]), o[5] = tanhf(headt[nb][2]), o[6] = tanhf(headt[nb][3]);
-                o[11] = zest_sigmoid(headt[nb][4]);            // row 8
-            }
-        } else if (head == ZEST_HEAD_DYNAMIC) {
-            o[7] = tanhf(headt[nb][0]), o[8] = tanhf(headt[nb][1]), o[9] = tanhf(headt[nb][2]);  // rows 4-6
-            o[10] = zest_sigmoid(headt[nb][3]);                // row 7
+        // tile row r sits in lane group r >> 2, element r & 3
+        if (grp == 0) {
+            o[0] = v2 ? zest_sigmoid(rgbt[cb][0]) : rgbt[cb][0];
+            o[1] = v2 ? zest_sigmoid(rgbt[cb][1]) : rgbt[cb][1];
+            o[2] = v2 ? zest_sigmoid(rgbt[cb][2]) : rgbt[cb][2];
+            o[3] = v2 ? fmaxf(headt[cb][0], 0.0f) : headt[cb][0];
+            if (head == ZEST_HEAD_BLEND) o[4] = zest_sigmoid(headt[cb][1]);
+            if (head == ZEST_HEAD_DYNAMIC)
+                o[4] = tanhf(headt[cb][1]), o[5] = tanhf(headt[cb][2]), o[6] = tanhf(headt[cb][3]);   // rows 1-3
+        } else if (head == ZEST_HEAD_DYNAMIC && grp == 1) {
+            o[7] = tanhf(headt[cb][0]), o[8] = tanhf(headt[cb][1]), o[9] = tanhf(headt[cb][2]);      // rows 4-6
+            o[10] = zest_sigmoid(headt[cb][3]);                                                      // row 7
+        } else if (head == ZEST_HEAD_DYNAMIC && grp == 2) {
+            o[11] = zest_sigmoid(headt[cb][0]);                                                      // row 8
         }
     }
 }
 
 template <int NB, int NT_PTS, bool MOD, int NT_FEAT>
-static int launch_one(const MlpPlan &p, const SlotMaps &maps, const void *tiles, const float *x, int M,
+static int launch_one(const MlpPlan &p, const PosMaps &maps, const void *tiles, const float *x, int M,
                       float *out, hipStream_t stream) {
     if (p.n_tiles != stream_units(NT_PTS, MOD ? NT_FEAT : 0)) {
         zest_set_error("zest_mlp_fwd(bf16): plan has %d stream units, kernel expects %d", p.n_tiles,
@@ -107,25 +109,30 @@ static int launch_one(const MlpPlan &p, const SlotMaps &maps, const void *tiles,
 
 int mlp_bf16_launch(const MlpPlan &p, const void *tiles, const float *x, int M, float *out,
                     hipStream_t stream) {
-    SlotMaps maps;
-    for (auto &r : maps.pts) r[0] = r[1] = -1;
-    for (auto &r : maps.feat) r[0] = r[1] = -1;
-    for (auto &r : maps.views) r[0] = r[1] = -1;
-    for (int s = 0; s < p.ns_pts; s++) maps.pts[s][0] = p.map_pts[2 * s], maps.pts[s][1] = p.map_pts[2 * s + 1];
-    for (int s = 0; s < p.ns_feat; s++) maps.feat[s][0] = p.map_feat[2 * s], maps.feat[s][1] = p.map_feat[2 * s + 1];
-    for (int s = 0; s < p.ns_views; s++) maps.views[s][0] = p.map_views[2 * s], maps.views[s][1] = p.map_views[2 * s + 1];
+    PosMaps maps;
+    for (auto &r : maps.pts) r = -1;
+    for (auto &r : maps.feat) r = -1;
+    for (auto &r : maps.views) r = -1;
+    if (p.ns_pts > 96 || p.ns_feat > 64 || p.ns_views > 32) {
+        zest_set_error("zest_mlp_fwd(bf16): operand of %d/%d/%d positions exceeds the kernel's tables",
+                       p.ns_pts, p.ns_feat, p.ns_views);
+        return (int)hipErrorInvalidValue;
+    }
+    for (int s = 0; s < p.ns_pts; s++) maps.pts[s] = p.map_pts[s];
+    for (int s = 0; s < p.ns_feat; s++) maps.feat[s] = p.map_feat[s];
+    for (int s = 0; s < p.ns_views; s++) maps.views[s] = p.map_views[s];
     const bool mod = p.desc.use_feat != 0;
     const int key = p.nt_pts * 10 + (mod ? p.nt_feat : 0);
     switch (key) {
         case 40: return launch_one<1, 4, false, 0>(p, maps, tiles, x, M, out, stream);
         case 42: return launch_one<1, 4, true, 2>(p, maps, tiles, x, M, out, stream);
-        case 43: return launch_one<1, 4, true, 3>(p, maps, tiles, x, M, out, stream);
+        case 44: return launch_one<1, 4, true, 4>(p, maps, tiles, x, M, out, stream);
         case 60: return launch_one<1, 6, false, 0>(p, maps, tiles, x, M, out, stream);
         case 62: return launch_one<1, 6, true, 2>(p, maps, tiles, x, M, out, stream);
-        case 63: return launch_one<1, 6, true, 3>(p, maps, tiles, x, M, out, stream);
+        case 64: return launch_one<1, 6, true, 4>(p, maps, tiles, x, M, out, stream);
     }
-    zest_set_error("zest_mlp_fwd(bf16): no kernel for %d point tiles / %d feature tiles "
-                   "(supported: 3..8 source views)", p.nt_pts, mod ? p.nt_feat : 0);
+    zest_set_error("zest_mlp_fwd(bf16): no kernel for %d point units / %d feature units per row "
+                   "block (supported: 1..14 source views)", p.nt_pts, mod ? p.nt_feat : 0);
     return (int)hipErrorInvalidValue;
 }
 

@@ -1,15 +1,19 @@
 // bf16 MFMA engine for the width-256 NeRF MLP: activations stay in registers.
 //
-// Orientation: Y^T = W X^T with v_mfma_f32_32x32x16_bf16.  A wave owns NB column blocks of
-// 32 samples (sample = lane & 31; both lane halves own the same sample).  The A operand is a
-// pre-packed 1 KiB weight tile (mlp_plan.h), the B operand 8 bf16 per lane = 8 "slots" of the
-// wave's activation operand.  A finished 32x32 accumulator tile (16 fp32 per lane, output
-// features on the register axis) is biased via its initial value, modulated, rectified,
-// rounded to bf16 pairs and IS two B-operand tiles of the next op: no LDS round trip and no
-// cross-lane traffic between layers (cdna_hip_programming.md section 3, "an accumulator tile
-// as the next MFMA's operand"; the k permutation that implies is folded into the packed
-// weights).  Row-blocks are the outer loop, so only one accumulator tile (plus one modulation
-// tile) per column block is live next to the 64-register input and output operands.
+// Orientation: Y^T = W X^T with v_mfma_f32_16x16x32_bf16 (this kernel is limited by board power,
+// not by issue cycles; at identical operand traffic this shape delivered 5-15 % more FLOP/s
+// here than 32x32x16, cf. MI355X_MICROARCH.md "Shape").  A wave owns NB blocks of 32 samples =
+// 2 NB column blocks of 16: lane l serves sample column l & 15 of every column block, as group
+// g = l >> 4 of four.  The A operand is a pre-packed 1 KiB weight tile (16 output rows x 32
+// k-positions, mlp_plan.h) and feeds one MFMA per column block; the B operand is one k-tile of
+// a column block's activations, 8 bf16 per lane (positions 8g .. 8g+7).  Two finished 16x16
+// accumulator tiles of a row block (4 fp32 per lane each: rows 4g .. 4g+3), biased via their
+// initial value, modulated, rectified and rounded to bf16 pairs, ARE one k-tile of the next
+// op's B operand: no LDS round trip and no cross-lane traffic between layers
+// (cdna_hip_programming.md section 3, "an accumulator tile as the next MFMA's operand"; the k
+// permutation that implies is folded into the packed weights).  Row blocks are the outer loop,
+// so only four small accumulators (plus four for the modulation) per 32 samples are live next
+// to the 64-register input and output operands.
 //
 // The weight stream (units of 1 KiB in consumption order, mlp_plan.h) comes from a `Tiles`
 // source: GlobalTiles reads units straight from global memory (standalone MLP kernel);
@@ -21,10 +25,12 @@
 #include "zest_common.cuh"
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) float v4f;
 typedef __attribute__((ext_vector_type(4))) unsigned v4u;
 typedef const __attribute__((address_space(1))) v4u *gptr_u4;        // global memory, 16-byte units
+typedef __attribute__((address_space(3))) int lds_int;                // an int in LDS
 
 namespace zest {
 
@@ -48,16 +54,17 @@ __device__ __forceinline__ f32x16 f32x16_from(const v4f b0, const v4f b1, const 
 // ---- weight source 1: global memory --------------------------------------------------------
 struct GlobalTiles {
     gptr_u4 base;          // wave-uniform: first unit of the stream
-    int lane, half;
+    int lane, grp;         // grp = lane >> 4
     __device__ __forceinline__ bf16x8 load(int unit) const {
         const v4u v = base[(size_t)unit * 64 + lane];
         return *reinterpret_cast<const bf16x8 *>(&v);
     }
-    // bias block `which` (0 = op bias, 1 = modulation bias) of header unit `unit`
-    __device__ __forceinline__ f32x16 load_bias(int unit, int which) const {
+    // bias block `which` (0 = op bias, 1 = modulation bias) of header unit `unit`: the four
+    // biases of this lane's accumulator rows 16 rt + 4 grp .. + 3
+    __device__ __forceinline__ f32x4 load_bias(int unit, int which, int rt) const {
         const __attribute__((address_space(1))) v4f *b =
-            (const __attribute__((address_space(1))) v4f *)(base + (size_t)unit * 64) + which * 8 + half * 4;
-        return f32x16_from(b[0], b[1], b[2], b[3]);
+            (const __attribute__((address_space(1))) v4f *)(base + (size_t)unit * 64) + which * 8 + rt * 4 + grp;
+        return *b;
     }
     __device__ __forceinline__ void finish(int, int) const {}
 };
@@ -86,11 +93,16 @@ struct RingTiles {
     static_assert(kChunk % NW == 0 && UNITS_A % kRingUnits == 0 && UNITS_B % kRingUnits == 0, "");
     char *ring;            // LDS, kRingUnits KiB, 16-byte aligned
     gptr_u4 src_a, src_b;  // the two nets' streams (src_b unused when UNITS_B == 0)
-    int lane, half, wave;  // wave: provably uniform (readfirstlane)
+    int lane, grp, wave;   // grp = lane >> 4; wave: provably uniform (readfirstlane)
     unsigned voff;         // (wave * kPieces * 64 + lane) * 16: this lane's byte offset in a chunk
     unsigned lds_wave_base; // LDS byte address of the ring + wave * kPieces * 1024
+#ifdef ZEST_RING_FLAGS     // rendezvous-free ring: per-slot counters in LDS instead of a barrier per chunk
+    unsigned flags;        // LDS byte address of 2 * kSlots ints, see off_landed / off_done
+    mutable int gen_base = 0;      // ring generations completed by earlier passes of this workgroup
+    mutable int poisoned = 0;      // a bounded wait ran out (never in a correct run): results are invalid
+#endif
 #ifdef ZEST_STAMPS         // diagnostic build: cycles spent in enter_chunk (DMA wait + barrier + issue)
-    mutable unsigned long long t_wait = 0, t_issue = 0;
+    mutable unsigned long long t_wait = 0, t_issue = 0, t_vm = 0;   // t_vm: the vmcnt part of t_wait
 #endif
 
     // LDS-DMA of this wave's pieces of a chunk.  Issued through inline asm so that only the
@@ -124,16 +136,131 @@ struct RingTiles {
                          "global_load_lds_dwordx4 %0, %1 offset:3072"
                          :: "v"(voff), "s"(sb), "s"(dst) : "memory", "m0");
     }
+#ifdef ZEST_RING_FLAGS
+    // Two monotonic counters per slot, each bumped once per wave and use of the slot:
+    //   landed[s]: this wave's DMA pieces of the chunk now in slot s are in LDS (published one
+    //              chunk early, when the wave enters the chunk before it)
+    //   done[s]:   this wave has issued its last read of the chunk in slot s
+    // A wave may read chunk q once landed[q % kSlots] == NW * (generation(q) + 1), and may
+    // refill slot t once done[t] == NW * generation(new occupant).  landed[s] and the done
+    // counter the same enter_chunk needs (slot s + kAhead) sit next to each other: one 8-byte
+    // read.  No wave ever waits for the others to ARRIVE anywhere: the two waves of a SIMD
+    // drift apart and one's MFMAs cover the other's waits, DMA issue and epilogues.
+    static_assert(kSlots >= kAhead + 2, "flag ring: a slot is refilled while laggards read its neighbours");
+    static constexpr int off_landed(int slot) { return 8 * (slot % kSlots); }
+    static constexpr int off_done(int slot) { return 8 * ((slot % kSlots - kAhead + kSlots) % kSlots) + 4; }
+    static __device__ void init_flags(int *f) {             // before the workgroup's first barrier
+        if (threadIdx.x < 2 * kSlots) f[threadIdx.x] = 0;
+        __syncthreads();
+        // the very first enter_chunk "finishes" a chunk that never was: pre-charge its counter
+        if (threadIdx.x == 0) f[off_done(kSlots - 1) / 4] = -NW;
+    }
+    // The flag traffic is inline asm on purpose: a C++ wait loop in every enter_chunk puts ~80
+    // loops into the unrolled network, after which hipcc no longer keeps the operand arrays in
+    // registers; an asm block is straight-line code to it.  Lane 0 does the adds (EXEC = 1).
+    // No VGPR is first written inside an asm block: hipcc inserts no MFMA->VALU wait states for
+    // asm (cdna guide 5.7), and a scratch register it hands out may be the destination of an MFMA
+    // still in flight (seen: the adds after the last rgb MFMA added an activation instead of 1).
+    // Constants come in as inputs and the read targets are initialised in C++.
+    template <int OFF_A, int OFF_B>
+    __device__ __forceinline__ void bump2() const {
+        unsigned long long save;
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\t"
+                     "ds_add_u32 %2, %1 offset:%3\n\tds_add_u32 %2, %1 offset:%4\n\ts_mov_b64 exec, %0"
+                     : "=&s"(save) : "v"(1u), "v"(flags), "i"(OFF_A), "i"(OFF_B) : "memory");
+    }
+    __device__ __forceinline__ void prologue() const {
+#pragma unroll
+        for (int c = 0; c < kAhead; c++) issue(c);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"((kAhead - 1) * kPieces) : "memory");
+        unsigned long long save;
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\t"
+                     "ds_add_u32 %2, %1 offset:%3\n\ts_mov_b64 exec, %0"
+                     : "=&s"(save) : "v"(1u), "v"(flags), "i"(off_landed(0)) : "memory");
+    }
+    __device__ __forceinline__ void next_pass() const { gen_base += kChunks / kSlots; }
+    // The two counters a chunk entry checks are read kPreRead units ahead of it (pre_read), with
+    // the tile reads around them hiding the LDS latency; the check itself is then scalar work
+    // on registers.  Only if the early values are short of the targets does the wave fall into
+    // the (bounded) re-read loop.
+    static constexpr int kPreRead = 5;
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    mutable v2i flag_pre = {0, 0};
+    __device__ __forceinline__ void pre_read(int chunk) const {
+        flag_pre = *(const volatile __attribute__((address_space(3))) v2i *)(flags + off_landed(chunk));
+    }
+    template <int OFF>
+    __device__ __forceinline__ void await(int need_l, int need_d) const {
+        unsigned va = (unsigned)flag_pre.x, vb = (unsigned)flag_pre.y;
+        int sa, sb, tries = 1 << 14;       // bounded: a protocol bug must not hang the GPU
+        asm volatile("0:\n\t"
+                     "v_readfirstlane_b32 %2, %0\n\t"
+                     "v_readfirstlane_b32 %3, %1\n\t"
+                     "s_nop 1\n\t"
+                     "s_cmp_ge_i32 %2, %6\n\t"
+                     "s_cselect_b32 %2, 1, 0\n\t"
+                     "s_cmp_ge_i32 %3, %7\n\t"
+                     "s_cselect_b32 %3, 1, 0\n\t"
+                     "s_and_b32 %2, %2, %3\n\t"
+                     "s_cbranch_scc1 1f\n\t"
+                     "s_sub_u32 %4, %4, 1\n\t"
+                     "s_cmp_eq_u32 %4, 0\n\t"
+                     "s_cbranch_scc1 1f\n\t"
+                     "s_sleep 1\n\t"
+                     "ds_read_b32 %0, %5 offset:%8\n\t"
+                     "ds_read_b32 %1, %5 offset:%9\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"
+                     "s_branch 0b\n\t"
+                     "1:"
+                     : "+v"(va), "+v"(vb), "=&s"(sa), "=&s"(sb), "+s"(tries)
+                     : "v"(flags), "s"(need_l), "s"(need_d), "i"(OFF), "i"(OFF + 4)
+                     : "memory", "scc");
+        if (tries == 0) poisoned = 1;
+    }
+    __device__ __forceinline__ void enter_chunk(int chunk) const {
+#ifdef ZEST_STAMPS
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
+        // own pieces of the NEXT chunk have landed (chunks chunk+2 .. chunk+kAhead-1 stay in flight);
+        // all reads of the previous chunk are issued (LDS operations of a wave execute in order)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"((kAhead - 2) * kPieces) : "memory");
+#ifdef ZEST_STAMPS
+        t_vm += __builtin_amdgcn_s_memtime() - t0;
+#endif
+        // (a switch, because the asm offsets must be literal constants; `chunk` is one only after
+        // unrolling - build with -mllvm -pragma-unroll-threshold raised, see build_hip.py)
+        const int need_l = NW * (gen_base + chunk / kSlots + 1), need_d = NW * (gen_base + (chunk + kAhead) / kSlots);
+        if (chunk % kChunks == 0) pre_read(chunk);           // first chunk of a pass: nothing ran ahead of it
+        switch (chunk % kSlots) {
+#define ZEST_CASE(S) case S: bump2<off_landed(S + 1), off_done(S + kSlots - 1)>(); await<off_landed(S)>(need_l, need_d); break;
+            ZEST_CASE(0) ZEST_CASE(1) ZEST_CASE(2) ZEST_CASE(3) ZEST_CASE(4) ZEST_CASE(5) ZEST_CASE(6) ZEST_CASE(7)
+            ZEST_CASE(8) ZEST_CASE(9) ZEST_CASE(10) ZEST_CASE(11) ZEST_CASE(12) ZEST_CASE(13) ZEST_CASE(14) ZEST_CASE(15)
+#undef ZEST_CASE
+        }
+        static_assert(kSlots <= 16, "extend the slot switch");
+#ifdef ZEST_STAMPS
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#endif
+        issue(chunk + kAhead);
+#ifdef ZEST_STAMPS
+        t_wait += t1 - t0, t_issue += __builtin_amdgcn_s_memtime() - t1;
+#endif
+    }
+#else
     __device__ __forceinline__ void prologue() const {
 #pragma unroll
         for (int c = 0; c < kAhead; c++) issue(c);
     }
+    __device__ __forceinline__ void next_pass() const {}
     __device__ __forceinline__ void enter_chunk(int chunk) const {
 #ifdef ZEST_STAMPS
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #endif
         // all but the youngest (kAhead-1)*kPieces of this wave's DMA pieces have landed
         asm volatile("s_waitcnt vmcnt(%0)" ::"i"((kAhead - 1) * kPieces) : "memory");
+#ifdef ZEST_STAMPS
+        t_vm += __builtin_amdgcn_s_memtime() - t0;
+#endif
 #ifndef ZEST_EXPERIMENT_NO_BARRIER      // timing experiment only: results are wrong without it
         __builtin_amdgcn_s_barrier();
 #endif
@@ -148,27 +275,52 @@ struct RingTiles {
         t_wait += t1 - t0, t_issue += __builtin_amdgcn_s_memtime() - t1;
 #endif
     }
+#endif
     __device__ __forceinline__ void touch(int unit) const {
         if (unit % kChunk == 0) enter_chunk(unit / kChunk);
+#ifdef ZEST_RING_FLAGS
+        if (unit % kChunk == kChunk - kPreRead) pre_read(unit / kChunk + 1);
+#endif
+    }
+    // LDS read addresses: exactly two base registers per access pattern (lower / upper 64 KiB of
+    // the ring, the reach of the 16-bit DS offset field), made opaque once.  Left to itself hipcc
+    // materialises every `const + lane * 16` beyond the first 64 KiB as a loop-invariant VGPR of
+    // its own: ~60 registers of addresses that crowd out operands and end in scratch.
+    mutable unsigned rd_lo = 0, rd_hi = 0, rb_lo = 0, rb_hi = 0;
+    __device__ __forceinline__ void init_addr() const {
+        const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)ring;
+        rd_lo = base + lane * 16, rd_hi = rd_lo + 65536, rb_lo = base + grp * 16, rb_hi = rb_lo + 65536;
+        asm volatile("" : "+v"(rd_lo), "+v"(rd_hi), "+v"(rb_lo), "+v"(rb_hi));
+    }
+    static_assert(kRingUnits <= 128, "two 64 KiB windows");
+    template <class T>
+    static __device__ __forceinline__ const __attribute__((address_space(3))) T *lds_at(unsigned addr) {
+        return (const __attribute__((address_space(3))) T *)(uintptr_t)addr;
     }
     __device__ __forceinline__ bf16x8 load(int unit) const {
         touch(unit);
 #ifdef ZEST_EXPERIMENT_NO_LDSREAD       // timing experiment only: one read per chunk
-        const v4u v = *reinterpret_cast<const v4u *>(ring + (unit / kChunk * kChunk % kRingUnits) * 1024 + lane * 16);
+        const int r = unit / kChunk * kChunk % kRingUnits;
 #else
-        const v4u v = *reinterpret_cast<const v4u *>(ring + (unit % kRingUnits) * 1024 + lane * 16);
+        const int r = unit % kRingUnits;
 #endif
+        const v4u v = *lds_at<v4u>((r < 64 ? rd_lo : rd_hi) + (r % 64) * 1024);
         return *reinterpret_cast<const bf16x8 *>(&v);
     }
-    __device__ __forceinline__ f32x16 load_bias(int unit, int which) const {
-        if (which == 0) touch(unit);          // the modulation block (which = 1) is read right after
-        const v4f *b = reinterpret_cast<const v4f *>(ring + (unit % kRingUnits) * 1024 + which * 128 + half * 64);
-        return f32x16_from(b[0], b[1], b[2], b[3]);
+    __device__ __forceinline__ f32x4 load_bias(int unit, int which, int rt) const {
+        if (which == 0 && rt == 0) touch(unit);     // the other blocks of the header are read right after
+        const int r = unit % kRingUnits;
+        return *lds_at<v4f>((r < 64 ? rb_lo : rb_hi) + (r % 64) * 1024 + which * 128 + rt * 64);
     }
     // walk the padding [unit, end) of a net's stream so every chunk is entered exactly once
     __device__ __forceinline__ void finish(int unit, int end) const {
 #pragma unroll
-        for (int u = (unit + kChunk - 1) / kChunk * kChunk; u < end; u += kChunk) enter_chunk(u / kChunk);
+        for (int u = (unit + kChunk - 1) / kChunk * kChunk; u < end; u += kChunk) {
+#ifdef ZEST_RING_FLAGS
+            pre_read(u / kChunk);
+#endif
+            enter_chunk(u / kChunk);
+        }
     }
     __device__ __forceinline__ void drain() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
@@ -189,51 +341,47 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
 // canonicalising v_max in front; med3 against a finite bound is not folded back into it)
 __device__ __forceinline__ float relu1(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 3.0e38f); }
 
-// 16 activated fp32 values of a tile -> the two bf16 operand tiles they form
-__device__ __forceinline__ void acc_to_operand(const f32x16 &v, bf16x8 &t0, bf16x8 &t1) {
-    unsigned w[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) w[j] = pack_bf16(v[2 * j], v[2 * j + 1]);
-    uint4 a = make_uint4(w[0], w[1], w[2], w[3]), b = make_uint4(w[4], w[5], w[6], w[7]);
-    t0 = *reinterpret_cast<bf16x8 *>(&a);
-    t1 = *reinterpret_cast<bf16x8 *>(&b);
-}
-
 template <int N>
-struct OpArr {              // N operand tiles; N = 0 allowed
+struct OpArr {              // N k-tiles of one column block's operand; N = 0 allowed
     bf16x8 t[N > 0 ? N : 1];
 };
 
 #ifndef ZEST_PREFETCH
-#define ZEST_PREFETCH 3        // weight tiles kept in flight ahead of the MFMA that consumes them
+#define ZEST_PREFETCH 3        // weight tiles kept in flight ahead of the MFMAs that consume them
 #endif
 constexpr int kPrefetch = ZEST_PREFETCH;
 
 // What is fetched ahead for one row block: its bias initialisers and its first tiles.
 template <bool MOD>
 struct RowBlockPre {
-    f32x16 bias, mbias;
+    f32x4 bias[2], mbias[2];      // per row tile
     bf16x8 win[kPrefetch];
 };
 
-// One Linear: NJB row blocks over the operand [A (NTA tiles) | B (NTB tiles)].
-//   MOD:  tile is modulated by the feature operand (NTF tiles) with the op's modulation tiles
-//   MODE: 0 = produce operand tiles into `out` (2 per row block), 1 = keep the accumulator of
-//         row block 0 in `keep` (head / rgb tiles)
-// The LDS reads are software-pipelined by hand, in source order, because hipcc leaves them
-// where they are written in a block this large: every tile is requested kPrefetch tiles before
-// the MFMA that uses it, and the NEXT row block's header and first tiles are requested before
-// the CURRENT epilogue, whose ~40 VALU instructions cover their latency.
-template <int NB, int NJB, int NTA, int NTB, bool MOD, int NTF, bool RELU, int MODE, class Tiles>
+// One Linear: NJB row blocks (32 outputs = row tiles 0, 1) over the operand
+// [A (NKA k-tiles) | B (NKB k-tiles)] of each of the CB column blocks.
+//   MOD:  the row block is modulated by the feature operand (NKF k-tiles) with the op's
+//         modulation tiles
+//   MODE: 0 = produce k-tile jb of `out`, 1 = keep row tile 0 of row block 0 in `keep`
+//         (head / rgb: lane group g holds rows 4g .. 4g+3)
+// Unit order inside a row block: header, then per k-tile the row tiles 0, 1 (modulation k-tiles
+// first): four independent accumulators per 32 samples take turns.  The LDS reads are
+// software-pipelined by hand, in source order: every tile is requested kPrefetch tiles before
+// the MFMAs that use it, and the NEXT row block's header and first tiles are requested before
+// the CURRENT epilogue, whose VALU instructions cover their latency.
+template <int CB, int NJB, int NKA, int NKB, bool MOD, int NKF, bool RELU, int MODE, class Tiles>
 __device__ __forceinline__ void engine_layer(const Tiles &tiles, int &unit, bool v2,
-                                             const OpArr<NTA> (&opa)[NB], const OpArr<NTB> (&opb)[NB],
-                                             const OpArr<NTF> (&opf)[NB], OpArr<16> (&out)[NB],
-                                             f32x16 (&keep)[NB]) {
-    constexpr int NM = MOD ? NTF : 0, T = NM + NTA + NTB;       // tiles per row block
+                                             const OpArr<NKA> (&opa)[CB], const OpArr<NKB> (&opb)[CB],
+                                             const OpArr<NKF> (&opf)[CB], OpArr<8> (&out)[CB],
+                                             f32x4 (&keep)[CB]) {
+    constexpr int NM = MOD ? 2 * NKF : 0, T = NM + 2 * (NKA + NKB);     // tiles per row block
     static_assert(T >= 1, "empty layer");
     auto preload = [&](RowBlockPre<MOD> &p, int u0) {           // u0: the row block's header unit
-        p.bias = tiles.load_bias(u0, 0);
-        if (MOD) p.mbias = tiles.load_bias(u0, 1);
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++) {
+            p.bias[rt] = tiles.load_bias(u0, 0, rt);
+            if (MOD) p.mbias[rt] = tiles.load_bias(u0, 1, rt);
+        }
 #pragma unroll
         for (int k = 0; k < kPrefetch; k++)
             if (k < T) p.win[k] = tiles.load(u0 + 1 + k);
@@ -243,87 +391,97 @@ __device__ __forceinline__ void engine_layer(const Tiles &tiles, int &unit, bool
 #pragma unroll
     for (int jb = 0; jb < NJB; jb++) {
         const int u0 = unit;
-        f32x16 acc[NB], macc[NB];
+        f32x4 acc[2][CB], macc[2][CB];
         bf16x8 win[kPrefetch];
 #pragma unroll
         for (int k = 0; k < kPrefetch; k++) win[k] = pre.win[k];
 #pragma unroll
-        for (int nb = 0; nb < NB; nb++) {
-            acc[nb] = pre.bias;
-            if (MOD) macc[nb] = pre.mbias;
-        }
+        for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+            for (int cb = 0; cb < CB; cb++) {
+                acc[rt][cb] = pre.bias[rt];
+                if (MOD) macc[rt][cb] = pre.mbias[rt];
+            }
 #pragma unroll
         for (int k = 0; k < T; k++) {
             const bf16x8 a = win[k % kPrefetch];
+            const int rt = k % 2, kt = (k < NM ? k : k - NM) / 2;          // compile-time after unrolling
 #pragma unroll
-            for (int nb = 0; nb < NB; nb++) {
+            for (int cb = 0; cb < CB; cb++) {
                 if (k < NM)
-                    macc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, opf[nb].t[k < NM ? k : 0], macc[nb], 0, 0, 0);
-                else if (k < NM + NTA)
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, opa[nb].t[(k >= NM && k < NM + NTA) ? k - NM : 0], acc[nb], 0, 0, 0);
+                    macc[rt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, opf[cb].t[k < NM ? kt : 0], macc[rt][cb], 0, 0, 0);
+                else if (kt < NKA)
+                    acc[rt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, opa[cb].t[(k >= NM && kt < NKA) ? kt : 0], acc[rt][cb], 0, 0, 0);
                 else
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, opb[nb].t[k >= NM + NTA ? k - NM - NTA : 0], acc[nb], 0, 0, 0);
+                    acc[rt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, opb[cb].t[(k >= NM && kt >= NKA) ? kt - NKA : 0], acc[rt][cb], 0, 0, 0);
             }
             if (k + kPrefetch < T) win[k % kPrefetch] = tiles.load(u0 + 1 + k + kPrefetch);
+#ifdef ZEST_SCHED_PIN
+            __builtin_amdgcn_sched_barrier(0);      // keep the hand-made read-ahead distance
+#endif
         }
         unit = u0 + 1 + T;
         if (jb + 1 < NJB) preload(pre, unit);                   // in flight during the epilogue
 #pragma unroll
-        for (int nb = 0; nb < NB; nb++) {
-            f32x16 v = acc[nb];
-            if (MOD) {
+        for (int cb = 0; cb < CB; cb++) {
+            float v[8];
 #pragma unroll
-                for (int i = 0; i < 16; i++) v[i] = v2 ? v[i] + macc[nb][i] : v[i] * macc[nb][i];
+            for (int i = 0; i < 8; i++) {
+                v[i] = acc[i >> 2][cb][i & 3];
+                if (MOD) v[i] = v2 ? v[i] + macc[i >> 2][cb][i & 3] : v[i] * macc[i >> 2][cb][i & 3];
+                if (RELU) v[i] = relu1(v[i]);
             }
-            if (RELU) {
-#pragma unroll
-                for (int i = 0; i < 16; i++) v[i] = relu1(v[i]);
+            if (MODE == 0) {
+                uint4 q = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]),
+                                     pack_bf16(v[6], v[7]));
+                out[cb].t[jb] = *reinterpret_cast<bf16x8 *>(&q);
+            } else if (jb == 0) {
+                keep[cb] = f32x4{v[0], v[1], v[2], v[3]};
             }
-            if (MODE == 0)
-                acc_to_operand(v, out[nb].t[2 * jb], out[nb].t[2 * jb + 1]);
-            else if (jb == 0)
-                keep[nb] = v;
         }
     }
 }
 
-// The whole network for NB column blocks, reading the stream from unit `unit` on (advanced to
-// the end of the net's padded stream).  pts/feat: encoder operands in plan slot order;
+// The whole network for NB blocks of 32 samples (CB = 2 NB column blocks), reading the stream
+// from unit `unit` on (advanced to the end of the net's padded stream).  pts/feat: encoder
+// operands in plan position order, NU_* = their stream units per row block = 2 x k-tiles;
 // `views_fn(views)` builds the direction operand when it is first needed (op 10) so that it does
-// not occupy registers through the trunk.  Results: head tile (row 0 alpha, rows 1.. extra
-// heads) and rgb tile (rows 0-2), raw.
-template <int NB, int NT_PTS, bool MOD, int NT_FEAT, class Tiles, class ViewsFn>
+// not occupy registers through the trunk.  Results per column block: head (lane group g: rows
+// 4g .. 4g+3 of the head tile; row 0 alpha, rows 1.. extra heads) and rgb (group 0: rows 0-2), raw.
+template <int NB, int NU_PTS, bool MOD, int NU_FEAT, class Tiles, class ViewsFn>
 __device__ __forceinline__ void engine_forward(const Tiles &tiles, int &unit, bool v2,
-                                               const OpArr<NT_PTS> (&pts)[NB],
-                                               const OpArr<NT_FEAT> (&feat)[NB], ViewsFn views_fn,
-                                               f32x16 (&head)[NB], f32x16 (&rgb)[NB]) {
-    OpArr<16> hA[NB], hB[NB];
-    OpArr<0> none[NB];
-    f32x16 unused[NB];
+                                               const OpArr<NU_PTS / 2> (&pts)[2 * NB],
+                                               const OpArr<NU_FEAT / 2> (&feat)[2 * NB], ViewsFn views_fn,
+                                               f32x4 (&head)[2 * NB], f32x4 (&rgb)[2 * NB]) {
+    constexpr int CB = 2 * NB, KP = NU_PTS / 2, KF = NU_FEAT / 2;
+    static_assert(NU_PTS % 2 == 0 && NU_FEAT % 2 == 0, "units per row block come in row-tile pairs");
+    OpArr<8> hA[CB], hB[CB];
+    OpArr<0> none[CB];
+    f32x4 unused[CB];
     const int unit0 = unit;
-    engine_layer<NB, 8, NT_PTS, 0, MOD, NT_FEAT, true, 0>(tiles, unit, v2, pts, none, feat, hA, unused);
-    engine_layer<NB, 8, 16, 0, MOD, NT_FEAT, true, 0>(tiles, unit, v2, hA, none, feat, hB, unused);
-    engine_layer<NB, 8, 16, 0, MOD, NT_FEAT, true, 0>(tiles, unit, v2, hB, none, feat, hA, unused);
-    engine_layer<NB, 8, 16, 0, MOD, NT_FEAT, true, 0>(tiles, unit, v2, hA, none, feat, hB, unused);
-    engine_layer<NB, 8, 16, 0, MOD, NT_FEAT, true, 0>(tiles, unit, v2, hB, none, feat, hA, unused);
-    engine_layer<NB, 8, NT_PTS, 16, MOD, NT_FEAT, true, 0>(tiles, unit, v2, pts, hA, feat, hB, unused);
-    engine_layer<NB, 8, 16, 0, MOD, NT_FEAT, true, 0>(tiles, unit, v2, hB, none, feat, hA, unused);
-    engine_layer<NB, 8, 16, 0, MOD, NT_FEAT, true, 0>(tiles, unit, v2, hA, none, feat, hB, unused);
+    engine_layer<CB, 8, KP, 0, MOD, KF, true, 0>(tiles, unit, v2, pts, none, feat, hA, unused);
+    engine_layer<CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hA, none, feat, hB, unused);
+    engine_layer<CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hB, none, feat, hA, unused);
+    engine_layer<CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hA, none, feat, hB, unused);
+    engine_layer<CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hB, none, feat, hA, unused);
+    engine_layer<CB, 8, KP, 8, MOD, KF, true, 0>(tiles, unit, v2, pts, hA, feat, hB, unused);
+    engine_layer<CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hB, none, feat, hA, unused);
+    engine_layer<CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hA, none, feat, hB, unused);
     // trunk output in hB
-    engine_layer<NB, 1, 16, 0, false, NT_FEAT, false, 1>(tiles, unit, v2, hB, none, feat, hA, head);
-    engine_layer<NB, 8, 16, 0, false, NT_FEAT, false, 0>(tiles, unit, v2, hB, none, feat, hA, unused);
-    OpArr<2> views[NB];
+    engine_layer<CB, 1, 8, 0, false, KF, false, 1>(tiles, unit, v2, hB, none, feat, hA, head);
+    engine_layer<CB, 8, 8, 0, false, KF, false, 0>(tiles, unit, v2, hB, none, feat, hA, unused);
+    OpArr<1> views[CB];
     views_fn(views);
-    engine_layer<NB, 4, 16, 2, false, NT_FEAT, true, 0>(tiles, unit, v2, hA, views, feat, hB, unused);
-    // rgb: 128 hidden features = first 8 tiles of hB
-    OpArr<8> h128[NB];
+    engine_layer<CB, 4, 8, 1, false, KF, true, 0>(tiles, unit, v2, hA, views, feat, hB, unused);
+    // rgb: 128 hidden features = first 4 k-tiles of hB
+    OpArr<4> h128[CB];
 #pragma unroll
-    for (int nb = 0; nb < NB; nb++)
+    for (int cb = 0; cb < CB; cb++)
 #pragma unroll
-        for (int k = 0; k < 8; k++) h128[nb].t[k] = hB[nb].t[k];
-    engine_layer<NB, 1, 8, 0, false, NT_FEAT, false, 1>(tiles, unit, v2, h128, none, feat, hA, rgb);
-    tiles.finish(unit, unit0 + stream_units(NT_PTS, MOD ? NT_FEAT : 0));
-    unit = unit0 + stream_units(NT_PTS, MOD ? NT_FEAT : 0);
+        for (int k = 0; k < 4; k++) h128[cb].t[k] = hB[cb].t[k];
+    engine_layer<CB, 1, 4, 0, false, KF, false, 1>(tiles, unit, v2, h128, none, feat, hA, rgb);
+    tiles.finish(unit, unit0 + stream_units(NU_PTS, MOD ? NU_FEAT : 0));
+    unit = unit0 + stream_units(NU_PTS, MOD ? NU_FEAT : 0);
 }
 
 // standalone launcher (mlp.hip -> zest_mlp_fwd)

@@ -8,18 +8,26 @@
 //   10    views_linears.0 on [feature | PE(dir)], relu
 //   11    rgb_linear
 // Work is done transposed, Y^T = W X^T: samples sit on the MFMA column/lane axis and the
-// output features of a 32x32 tile in its accumulator registers, so a tile's activations
-// feed the next op's B operand without leaving the lane.
+// output features of a tile in its accumulator registers, so a tile's activations feed the
+// next op's B operand without leaving the lane.
 //
-// Operands are sequences of SLOTS.  A slot holds one value per lane, i.e. two features:
-// feature(slot, half) for the lane halves 0-31 / 32-63, which both own sample lane&31.
-// A TILE is 1 KiB of packed weights covering SPT slots (8 for bf16 = one 32x32x16 MFMA,
-// 4 for f32 = four 32x32x2 MFMAs): lane l, element e holds
-//   W[row0 + (l & 31)][col(feature(tile*SPT + e, l >> 5))]     (0 outside the matrix).
+// fp32 kernel (ORDER_NATURAL).  Operands are sequences of SLOTS.  A slot holds one value per
+// lane, i.e. two features: feature(slot, half) for the lane halves 0-31 / 32-63, which both own
+// sample lane&31.  A TILE is 1 KiB of packed weights covering 4 slots (four 32x32x2 MFMAs):
+// lane l, element e holds W[row0 + (l & 31)][col(feature(tile*4 + e, l >> 5))] (0 outside).
+//
+// bf16 engine (ORDER_ACC), built on v_mfma_f32_16x16x32_bf16 (measured ~5-15 % more FLOP/s than
+// the 32x32x16 shape on this power-limited kernel at identical operand traffic): an operand is a
+// sequence of k-tiles of 32 POSITIONS; lane l (sample column l & 15, group g = l >> 4) holds
+// positions 8g .. 8g+7 of each k-tile as one bf16x8.  A stream unit is the 16 x 32 weight tile
+// of one MFMA A operand: lane l, element e holds W[row0 + (l & 15)][feature(kt*32 + 8g + e)].
+// A row block of 32 outputs = two row tiles; a finished pair of 16x16 accumulator tiles
+// (lane: rows 4g..4g+3 of each) is, rounded to bf16, exactly one k-tile of the next layer.
 // The stream is laid out in consumption order: for op, for row-block jb:
 // [header] [modulation tiles over the feature operand] then one run of tiles per operand
-// segment.  A bias block is 128 bytes: the accumulator initialiser [half][16] =
-// bias[32 jb + (i&3) + 8 (i>>2) + 4 half].
+// segment (ORDER_ACC: per k-tile the row tiles 0, 1).  A bias block is 128 bytes: ORDER_NATURAL
+// the accumulator initialiser [half][16] = bias[32 jb + (i&3) + 8 (i>>2) + 4 half]; ORDER_ACC
+// bias[32 jb .. 32 jb + 31] in order.
 //   ORDER_NATURAL (fp32 kernel): no headers; blocks live in a separate bias area in front of
 //     the tiles, the eight modulation blocks first, then one per (op, jb).
 //   ORDER_ACC (bf16 engine): the header is one 1 KiB unit in the stream itself holding the
@@ -41,7 +49,7 @@ constexpr int kStreamAlign = 128;  // units (KiB): ring size the bf16 stream is 
 
 // slot-order conventions for operands that are produced from accumulator tiles
 enum SlotOrder {
-    ORDER_ACC = 0,      // slot 16T+i <-> feature 32T + (i&3) + 8(i>>2) + 4h   (register engine)
+    ORDER_ACC = 0,      // position 32kt+8g+e <-> feature 32kt + (e<4 ? 4g+e : 16+4g+e-4)   (register engine)
     ORDER_NATURAL = 1,  // tile of 4 slots over features k0..k0+7: slot j <-> k0 + 4h + j
 };
 
@@ -73,8 +81,9 @@ struct MlpPlan {
     int n_tiles, n_bias_blocks;    // n_tiles includes headers and tail padding
     size_t bias_bytes, bytes;      // bias area (padded to 1 KiB) and total
     OpPlan op[kNumOps];
-    // feature index (column within the operand's own input range) per slot and half; -1 = pad
-    std::vector<int16_t> map_pts, map_feat, map_views;     // [ns][2]
+    // feature index (column within the operand's own input range), -1 = pad:
+    // ORDER_NATURAL per slot and half [ns][2], ORDER_ACC per position [ns]
+    std::vector<int16_t> map_pts, map_feat, map_views;
     // gather tables for the packer: per packed weight element / bias float, source
     // (param_slot << 24 | element offset), 0xFFFFFFFF = zero
     std::vector<uint32_t> tile_src, bias_src;

@@ -8,31 +8,40 @@ namespace {
 
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
-// positional encoding of C coordinates with L bands, reference column order
-// [x(C), sin(2^0 x)(C), cos(2^0 x)(C), sin(2^1 x)(C), ...] (networks.py:60-65)
-void pe_map_acc(int C, int L, int ns, std::vector<int16_t> &m) {
-    m.assign((size_t)ns * 2, -1);
-    for (int q = 0; q < L * C; q++) {
-        const int band = q / C, coord = q % C;
-        m[2 * q] = (int16_t)(C + 2 * C * band + coord);           // half 0: sin
-        m[2 * q + 1] = (int16_t)(C + 2 * C * band + C + coord);   // half 1: cos
-    }
-    for (int p = 0; p < (C + 1) / 2; p++) {                       // raw coordinates, two per slot
-        const int q = L * C + p;
-        m[2 * q] = (int16_t)(2 * p);
-        m[2 * q + 1] = (int16_t)(2 * p + 1 < C ? 2 * p + 1 : -1);
+// ---- ORDER_ACC operand maps: one feature index per POSITION = kt*32 + 8*g + e (k-tile kt of
+// 32 operand values, lane group g = lane >> 4, element e of the lane's 8 bf16), -1 = zero pad.
+//
+// positional encoding of C coordinates with L (even) bands, reference column order
+// [x(C), sin(2^0 x)(C), cos(2^0 x)(C), sin(2^1 x)(C), ...] (networks.py:60-65).
+// m = 8*kt + e enumerates (band pair, coordinate): m = bp*C + c for m < (L/2)*C; the lane
+// group picks the band of the pair (g >> 1) and sin / cos (g & 1), so a lane's eight values
+// differ only in compile-time constants.  m = (L/2)*C holds the raw coordinates, one per group.
+void pe_map_acc(int C, int L, int npos, std::vector<int16_t> &m) {
+    m.assign((size_t)npos, -1);
+    for (int pos = 0; pos < npos; pos++) {
+        const int kt = pos / 32, g = (pos % 32) / 8, e = pos % 8, mm = 8 * kt + e;
+        if (mm < (L / 2) * C) {
+            const int band = 2 * (mm / C) + (g >> 1), coord = mm % C;
+            m[pos] = (int16_t)(C + 2 * C * band + ((g & 1) ? C : 0) + coord);
+        } else if (mm == (L / 2) * C) {
+            m[pos] = (int16_t)(g < C ? g : -1);
+        }
     }
 }
 
-void feat_map_acc(int V, int ns, std::vector<int16_t> &m) {
-    m.assign((size_t)ns * 2, -1);
-    for (int q = 0; q < 4; q++) m[2 * q] = (int16_t)q, m[2 * q + 1] = (int16_t)(q + 4);
-    for (int p = 0; p < (V + 1) / 2; p++)
-        for (int c = 0; c < 4; c++) {
-            const int q = 4 + 4 * p + c;
-            m[2 * q] = (int16_t)(8 + 8 * p + c);
-            m[2 * q + 1] = (int16_t)(2 * p + 1 < V ? 8 + 8 * p + 4 + c : -1);
+// feature operand: 4-channel quads, quad index 8*kt + 2*g + (e >> 2):
+// 0 = volume channels 0-3, 2 = volume channels 4-7, 1 = view 0, 3 = view 1, q >= 4 = view q-2
+void feat_map_acc(int V, int npos, std::vector<int16_t> &m) {
+    m.assign((size_t)npos, -1);
+    for (int pos = 0; pos < npos; pos++) {
+        const int kt = pos / 32, g = (pos % 32) / 8, e = pos % 8, q = 8 * kt + 2 * g + (e >> 2), c = e & 3;
+        if (q == 0) m[pos] = (int16_t)c;
+        else if (q == 2) m[pos] = (int16_t)(4 + c);
+        else {
+            const int view = q == 1 ? 0 : (q == 3 ? 1 : q - 2);
+            if (view < V) m[pos] = (int16_t)(8 + 4 * view + c);
         }
+    }
 }
 
 void natural_map(int width, int spt, int ntiles, std::vector<int16_t> &m) {
@@ -45,10 +54,13 @@ void natural_map(int width, int spt, int ntiles, std::vector<int16_t> &m) {
             }
 }
 
+// hidden operands: (slot, half) for ORDER_NATURAL; for ORDER_ACC `slot` is a position and the
+// k-tile kt is the row block that produced it: e < 4 from its row tile 0, e >= 4 from row tile 1,
+// accumulator rows 4g .. 4g+3 of the lane group
 inline int h_feature(int order, int spt, int slot, int half) {
     if (order == ORDER_ACC) {
-        const int T = slot / 16, i = slot % 16;
-        return 32 * T + (i & 3) + 8 * (i >> 2) + 4 * half;
+        const int kt = slot / 32, g = (slot % 32) / 8, e = slot % 8;
+        return 32 * kt + (e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4));
     }
     const int t = slot / spt, j = slot % spt;
     return t * 2 * spt + spt * half + j;
@@ -79,10 +91,11 @@ bool build_plan(const zest_mlp_desc &d, int precision, int order, MlpPlan *P, co
     p.spt = precision == ZEST_PREC_BF16 ? 8 : 4;
     const int spt = p.spt, C = d.in_ch_pts == 63 ? 3 : 4, V = d.use_feat ? (F - 8) / 4 : 0;
     if (order == ORDER_ACC) {
-        p.ns_pts = round_up(10 * C + (C + 1) / 2, 8);
-        p.ns_views = 16;
-        p.ns_feat = d.use_feat ? round_up(4 + 4 * ((V + 1) / 2), 8) : 0;
-        if (d.use_feat && p.ns_feat < 16) p.ns_feat = 16;      // engine variants: 2 or 3 tiles
+        // "slots" are positions here and a tile (16 rows x 32 positions) covers half a k-tile's
+        // rows: ns / 16 units per row block of 32 outputs
+        p.ns_pts = 32 * ((5 * C + 1 + 7) / 8);                 // 64 (xyz) / 96 (xyzt)
+        p.ns_views = 32;
+        p.ns_feat = d.use_feat ? round_up(4 * (2 + V), 32) : 0;  // 32 up to 6 views, 64 up to 14
         pe_map_acc(C, 10, p.ns_pts, p.map_pts);
         pe_map_acc(3, 4, p.ns_views, p.map_views);
         if (d.use_feat) feat_map_acc(V, p.ns_feat, p.map_feat);
@@ -94,8 +107,9 @@ bool build_plan(const zest_mlp_desc &d, int precision, int order, MlpPlan *P, co
         natural_map(27, spt, p.ns_views / spt, p.map_views);
         if (d.use_feat) natural_map(F, spt, p.ns_feat / spt, p.map_feat);
     }
-    p.nt_pts = p.ns_pts / spt, p.nt_views = p.ns_views / spt, p.nt_feat = p.ns_feat / spt;
-    p.nt_h = 128 / spt, p.nt_h128 = 64 / spt;
+    const int spu = order == ORDER_ACC ? 16 : spt;          // operand slots / positions per stream unit
+    p.nt_pts = p.ns_pts / spu, p.nt_views = p.ns_views / spu, p.nt_feat = p.ns_feat / spu;
+    p.nt_h = order == ORDER_ACC ? 16 : 128 / spt, p.nt_h128 = order == ORDER_ACC ? 8 : 64 / spt;
 
     // ---- op table ----------------------------------------------------------------------
     p.headers = order == ORDER_ACC ? 1 : 0;
@@ -146,13 +160,25 @@ bool build_plan(const zest_mlp_desc &d, int precision, int order, MlpPlan *P, co
         for (int k = 0; k < sg.ntiles; k++, t++)
             for (int l = 0; l < 64; l++)
                 for (int e = 0; e < spt; e++) {
-                    const int slot = k * spt + e, half = l >> 5, row = 32 * jb + (l & 31);
-                    int feat;
-                    switch (sg.kind) {
-                        case SEG_PTS: feat = p.map_pts[2 * slot + half]; break;
-                        case SEG_FEAT: feat = p.map_feat[2 * slot + half]; break;
-                        case SEG_VIEWS: feat = p.map_views[2 * slot + half]; break;
-                        default: feat = h_feature(order, spt, slot, half);
+                    int slot, half, row, feat;
+                    if (order == ORDER_ACC) {
+                        // unit k of the segment: k-tile k/2, row tile k%2 (16 rows x 32 positions);
+                        // lane l, element e: row l&15, position 8*(l>>4) + e of the k-tile
+                        slot = (k / 2) * 32 + 8 * (l >> 4) + e, half = 0, row = 32 * jb + 16 * (k % 2) + (l & 15);
+                        switch (sg.kind) {
+                            case SEG_PTS: feat = p.map_pts[slot]; break;
+                            case SEG_FEAT: feat = p.map_feat[slot]; break;
+                            case SEG_VIEWS: feat = p.map_views[slot]; break;
+                            default: feat = h_feature(order, spt, slot, 0);
+                        }
+                    } else {
+                        slot = k * spt + e, half = l >> 5, row = 32 * jb + (l & 31);
+                        switch (sg.kind) {
+                            case SEG_PTS: feat = p.map_pts[2 * slot + half]; break;
+                            case SEG_FEAT: feat = p.map_feat[2 * slot + half]; break;
+                            case SEG_VIEWS: feat = p.map_views[2 * slot + half]; break;
+                            default: feat = h_feature(order, spt, slot, half);
+                        }
                     }
                     RowSrc rs = is_mod ? RowSrc{ZEST_P_PTS_BIAS, row} : row_src(param_of_rows_op, row);
                     if (feat < 0 || rs.param < 0) continue;
@@ -163,7 +189,10 @@ bool build_plan(const zest_mlp_desc &d, int precision, int order, MlpPlan *P, co
     auto emit_bias_to = [&](std::vector<uint32_t> &dst, size_t at, int o, int jb, bool is_mod) {
         for (int h = 0; h < 2; h++)
             for (int i = 0; i < 16; i++) {
-                const int row = 32 * jb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                // ORDER_ACC: the 32 biases of the row block in natural order (a lane reads rows
+                // 16 rt + 4 g .. +3 of them); ORDER_NATURAL: 32x32 accumulator register order
+                const int row = order == ORDER_ACC ? 32 * jb + 16 * h + i
+                                                   : 32 * jb + (i & 3) + 8 * (i >> 2) + 4 * h;
                 RowSrc rs = is_mod ? RowSrc{ZEST_P_PTS_BIAS, row} : row_src(o, row);
                 if (rs.param < 0) continue;
                 dst[at + h * 16 + i] = ((uint32_t)rs.param << 24) | rs.row;

@@ -286,13 +286,13 @@ extern "C" int zest_mlp_train_fwd(const zest_mlp_desc *desc, const float *const 
     {
         float *brow = nxt + (long long)M * HW;      // 16 floats of scratch behind the view activations
         EW(fill_kernel, 16, brow, 16, 0.f);
-        hipMemcpyAsync(brow, p.b[ZEST_P_RGB], 3 * sizeof(float), hipMemcpyDeviceToDevice, st);
-        hipMemcpyAsync(brow + 3, p.b[ZEST_P_ALPHA], sizeof(float), hipMemcpyDeviceToDevice, st);
+        (void)hipMemcpyAsync(brow, p.b[ZEST_P_RGB], 3 * sizeof(float), hipMemcpyDeviceToDevice, st);
+        (void)hipMemcpyAsync(brow + 3, p.b[ZEST_P_ALPHA], sizeof(float), hipMemcpyDeviceToDevice, st);
         if (s.head == ZEST_HEAD_BLEND)
-            hipMemcpyAsync(brow + 4, p.b[ZEST_P_HEAD0], sizeof(float), hipMemcpyDeviceToDevice, st);
+            (void)hipMemcpyAsync(brow + 4, p.b[ZEST_P_HEAD0], sizeof(float), hipMemcpyDeviceToDevice, st);
         if (s.head == ZEST_HEAD_DYNAMIC) {
-            hipMemcpyAsync(brow + 4, p.b[ZEST_P_HEAD0], 6 * sizeof(float), hipMemcpyDeviceToDevice, st);
-            hipMemcpyAsync(brow + 10, p.b[ZEST_P_HEAD1], 2 * sizeof(float), hipMemcpyDeviceToDevice, st);
+            (void)hipMemcpyAsync(brow + 4, p.b[ZEST_P_HEAD0], 6 * sizeof(float), hipMemcpyDeviceToDevice, st);
+            (void)hipMemcpyAsync(brow + 10, p.b[ZEST_P_HEAD1], 2 * sizeof(float), hipMemcpyDeviceToDevice, st);
         }
         EW(bias_act_kernel, (long long)M * 16, hp, brow, (const float *)nullptr, (float *)nullptr, (long long)M * 16,
            16, 0, 0);

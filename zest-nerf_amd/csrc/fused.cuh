@@ -111,6 +111,9 @@ __device__ __forceinline__ void encode_feat_operand(const FusedNet &n, const flo
         const bool on = view < n.V;
         dst[0] = on ? o.x : 0.f, dst[1] = on ? o.y : 0.f, dst[2] = on ? o.z : 0.f, dst[3] = on ? o.w : 0.f;
     };
+#ifdef ZEST_EXPERIMENT_NO_GATHER      // timing experiment only: features are zero
+    valid = false;
+#endif
     if (valid) {
         if (grp < 2) {
             // Trilinear lookup of this group's four channels.  Branch-free: out-of-volume corners

@@ -151,3 +151,28 @@ def test_mlp_ragged_batch(hip):
         for M in (1, 31, 45):
             y = zh.mlp_fwd(desc, prec, packed, G(inp["x"])[0, :M])
             close(y, gold[:M], atol=tol[0], rtol=tol[1], name="M=%d" % M)
+
+
+@pytest.mark.parametrize("V", [1, 2, 5, 6, 7, 11, 14])
+def test_mlp_view_counts(hip, V):
+    """Feature operand layouts other than the fixtures' (V = 3, 4, 8): one k-tile up to 6 source
+    views (all four lane groups used from V = 5 on), two k-tiles up to 14.  Checked against the
+    oracle (pinned by the fixtures) on seeded inputs; both MFMA kernels."""
+    import torch
+    import zest_hip as zh
+    from oracle import zest_oracle as zo
+    import oracle_run as orun
+    import zest_synth as zs
+    Fd, M = 8 + 4 * V, 80
+    lay = zs.mlp_layout(gc.PE_PTS, gc.PE_DIR, Fd, False, True, True)
+    state = zs.fill_mlp_state(lay, 700 + V)
+    x = zs.rng(800 + V).uniform(-1, 1, size=(M, gc.PE_PTS + Fd + gc.PE_DIR)).astype(np.float32)
+    with torch.no_grad():
+        want = zo.mlp_forward(orun.state_t(state, torch.float32), torch.from_numpy(x),
+                              orun.spec_of(gc.PE_PTS, Fd, False, True, True)).numpy()
+    desc = zh.MlpDesc(gc.PE_PTS, Fd, gc.PE_DIR, 1, 0, zh.HEAD_NONE)
+    tab = zh.param_table({k: G(v) for k, v in state.items()}, desc)
+    y32 = zh.mlp_fwd(desc, zh.PREC_F32, zh.mlp_pack(desc, zh.PREC_F32, tab), G(x))
+    close(y32, want, name="fp32 V=%d" % V)
+    y16 = zh.mlp_fwd(desc, zh.PREC_BF16, zh.mlp_pack(desc, zh.PREC_BF16, tab), G(x))
+    close(y16, want, atol=3e-2 * np.abs(want).max(), rtol=3e-2, name="bf16 V=%d" % V)

@@ -210,3 +210,33 @@ def test_ray_permutation_commutes(hip):
     b = zest_hip.composite(G(inp["raw"][perm]), G(inp["z"][perm]), G(inp["rays_dir"][perm]))
     for x, y in zip(a, b):
         assert torch.equal(x[torch.from_numpy(perm).cuda()], y)
+
+
+@pytest.mark.parametrize("V", [1, 6, 7, 14])
+def test_fused_view_counts(hip, V):
+    """Fused renderer with feature operands of one k-tile (V <= 6) and two (V <= 14), against the
+    per-op bf16 path and the oracle on a seeded scene with V source views."""
+    import networks
+    import renderer
+    import oracle_run as orun
+    sc = gc.render_inputs(900 + V, R=24, S=40, V=V, use_mvs=True)
+    ns, _ = build_nets(sc)
+    cam = {"w2cs": G(sc["w2cs"]), "intrinsics": G(sc["intrinsics"])}
+
+    def call(maps_only):
+        args = SimpleNamespace(netchunk=1024, feat_dim=sc["feat_dim"], feat_dim_dy=24, img_downscale=1.0,
+                               use_color_volume=False, net_type="v0", precision=16, zest_maps_only=maps_only)
+        with torch.no_grad():
+            return renderer.rendering(
+                args, G(sc["rays_pts"]), G(sc["rays_ndc"]), G(sc["depth_candidates"]), G(sc["rays_dir"]),
+                volume_feature_static=G(sc["vol_static"]), imgs=G(sc["imgs"]), im_cam_mat=cam,
+                network_fn=ns, embedding_pts=networks.Embedding(3, 10),
+                embedding_xyzt=networks.Embedding(4, 10), embedding_dir=networks.Embedding(3, 4),
+                ref_frame_idx=gc.REF_FRAME_IDX, num_frames=gc.NUM_FRAMES, scene_flow=False, val=True)
+    fused, perop = call(True), call(False)
+    want = orun.oracle_render(dict(val=True), sc)
+    for k in ("rgb_map", "depth_map"):
+        close(fused[k][0], perop[k][0].cpu().numpy(), atol=3e-2 if "depth" in k else 4e-3, rtol=0,
+              name="fused~perop/%s V=%d" % (k, V))
+        close(fused[k][0], want[k].numpy(), atol=6e-2 if "depth" in k else 2e-2, rtol=0,
+              name="fused~oracle/%s V=%d" % (k, V))

@@ -105,6 +105,29 @@ int zest_embed_fwd(const float *x, int M, int C, int L, float *y, void *stream);
 int zest_volume_to_cl(const float *vol, int D, int H, int W, float *vol_cl, void *stream);
 int zest_images_to_cl(const float *imgs, int V, int H, int W, float *imgs_cl, void *stream);
 
+/* ---- MVS volume builder: plane-sweep cost volume --------------------
+ * zest_nchw_to_nhwc: [N,C,H,W] -> [N,H,W,C] (feature maps of FeatureNet, reference
+ * networks.py:962-1001, to channels-last: one bilinear tap = C contiguous floats).
+ *
+ * zest_volume_cost_fwd: MVSNet.build_volume_cost (reference networks.py:1077-1140), batch 1.
+ *   feats_cl [V,H,W,32], imgs_cl [V,H,W,4] (images already resized to H x W, rgb + pad),
+ *   proj [V-1,3,4] = src_proj @ ref_proj_inv of source views 1..V-1, depth [D] plane depths.
+ *   -> img_feat [3V+32, D, H+2pad, W+2pad]: reference image, warped source images, variance of
+ *   the (warped) features over the views whose projection is in frame; in_masks
+ *   [V, D, H+2pad, W+2pad].  The reference leaves channels 0-2 of the padding ring
+ *   uninitialised (torch.empty, networks.py:1097-1099); they are written as 0 here.
+ *
+ * zest_homo_warp_fwd: utils.homo_warp (reference utils.py:49-99).  src [C,H,W]; either
+ *   proj [3,4] + depth [D] (grid_out [D,Hp,Wp,2] receives the normalised sampling positions)
+ *   or grid_in [D,Hp,Wp,2] from an earlier call; warped [C,D,Hp,Wp]. */
+int zest_nchw_to_nhwc(const float *in, int N, int C, int H, int W, float *out, void *stream);
+int zest_volume_cost_fwd(const float *feats_cl, const float *imgs_cl, const float *proj,
+                         const float *depth, int V, int C, int D, int H, int W, int pad,
+                         float *img_feat, float *in_masks, void *stream);
+int zest_homo_warp_fwd(const float *src, const float *proj, const float *depth, const float *grid_in,
+                       int C, int D, int H, int W, int Hp, int Wp, int pad, float *warped,
+                       float *grid_out, void *stream);
+
 /* Trilinear lookup, zero padding, align_corners: index_point_feature
  * (reference utils.py:433-459).  vol_cl [D,H,W,8]; ndc [M,3] -> out [M,8]. */
 int zest_volume_lookup_fwd(const float *vol_cl, int D, int H, int W, const float *ndc, int M,

@@ -389,6 +389,70 @@ def sample_rays(xs, ys, K_tgt, c2w_tgt, w2c_ref, K_ref, near_tgt, far_tgt, near_
     return d, z, pts, ndc
 
 
+# ----------------------------------------------------- plane sweep (8(f) row 3)
+# Pinning: the reference's homo_warp builds its pixel grid with kornia.create_meshgrid, which
+# is not installed here, so only its sampling half (a given src_grid -> F.grid_sample, zero
+# padding, align_corners; utils.py:91-98) is pinned by a reference-generated fixture
+# (tests/golden/homo_warp.npz).  plane_grid and volume_cost below restate utils.py:57-89 and
+# networks.py:1077-1140 from the source text: PARITY UNPINNED for those two.
+def plane_grid(proj, depth, H, W, pad=0):
+    """proj [3,4] = src_proj @ ref_proj_inv, depth [D] -> normalised source positions
+    [D, H+2pad, W+2pad, 2] of every reference pixel (x - pad, y - pad) on every depth plane.
+
+    Restates homo_warp, /root/reference/utils.py:57-89 (create_meshgrid(normalized=False) is
+    the integer pixel grid, x fastest)."""
+    Hp, Wp = H + 2 * pad, W + 2 * pad
+    ys, xs = torch.meshgrid(torch.arange(Hp, dtype=proj.dtype), torch.arange(Wp, dtype=proj.dtype), indexing="ij")
+    ref = torch.stack([xs.reshape(-1) - pad, ys.reshape(-1) - pad, torch.ones(Hp * Wp, dtype=proj.dtype)])  # [3, HW]
+    R, T = proj[:, :3], proj[:, 3:]
+    ref_d = ref.repeat(1, depth.shape[0])                                         # [3, D*HW]
+    dv = depth[:, None].expand(-1, Hp * Wp).reshape(1, -1)
+    src = R @ ref_d + T / dv
+    g = src[:2] / src[2:]
+    gx = g[0] / ((W - 1) / 2) - 1
+    gy = g[1] / ((H - 1) / 2) - 1
+    return torch.stack([gx, gy], -1).view(depth.shape[0], Hp, Wp, 2)
+
+
+def grid_warp(src, grid):
+    """src [C,H,W], grid [D,Hp,Wp,2] -> [C,D,Hp,Wp]: bilinear, zero padding, align_corners.
+
+    Restates the sampling half of homo_warp, /root/reference/utils.py:91-98."""
+    D, Hp, Wp = grid.shape[:3]
+    out = F.grid_sample(src[None], grid.reshape(1, D, Hp * Wp, 2), mode="bilinear", padding_mode="zeros",
+                        align_corners=True)
+    return out.view(src.shape[0], D, Hp, Wp)
+
+
+def volume_cost(imgs, feats, proj_mats, depth, pad=0):
+    """imgs [V,3,Hi,Wi], feats [V,C,H,W], proj_mats [V,3,4], depth [D] ->
+    (img_feat [3V+C, D, Hp, Wp], in_masks [V, D, Hp, Wp]).
+
+    Restates MVSNet.build_volume_cost, /root/reference/networks.py:1077-1140 (inference branch;
+    the training branch is the same arithmetic out of place).  Channels 0-2 of the padding
+    ring, which the reference leaves uninitialised, are 0."""
+    V, C, H, W = feats.shape
+    D, Hp, Wp = depth.shape[0], H + 2 * pad, W + 2 * pad
+    ref = F.pad(feats[0], (pad, pad, pad, pad)) if pad > 0 else feats[0]
+    img_feat = torch.zeros(3 * V + C, D, Hp, Wp, dtype=feats.dtype)
+    imgs_lr = F.interpolate(imgs, (H, W), mode="bilinear", align_corners=False)
+    img_feat[:3, :, pad:H + pad, pad:W + pad] = imgs_lr[0][:, None].expand(-1, D, -1, -1)
+    vol_sum = ref[:, None].repeat(1, D, 1, 1)
+    vol_sq = vol_sum ** 2
+    masks = torch.ones(V, D, Hp, Wp, dtype=feats.dtype)
+    for i in range(1, V):
+        grid = plane_grid(proj_mats[i], depth, H, W, pad)
+        warped = grid_warp(feats[i], grid)
+        img_feat[3 * i:3 * i + 3] = grid_warp(imgs_lr[i], grid)
+        inside = (grid > -1.0) & (grid < 1.0)
+        masks[i] = (inside[..., 0] & inside[..., 1]).to(feats.dtype)
+        vol_sum = vol_sum + warped
+        vol_sq = vol_sq + warped ** 2
+    count = 1.0 / masks.sum(0, keepdim=True)
+    img_feat[-C:] = vol_sq * count - (vol_sum * count) ** 2
+    return img_feat, masks
+
+
 def num_threads():
     return torch.get_num_threads()
 

@@ -102,6 +102,27 @@ def mlp_inputs(seed, variant, M=64):
     return dict(state=state, x=x, P=P, Fd=Fd, sceneflow=sf, static=st, use_mvs=mvs, net_type=nt)
 
 
+# --------------------------------------------------------------- plane-sweep cases
+def cost_inputs(seed, V=3, H=18, W=24, D=6, pad=2, spread=0.35):
+    """Feature maps, images and homographies src_proj @ ref_proj_inv at feature resolution for
+    MVSNet.build_volume_cost / utils.homo_warp.  The spread moves part of the sweep out of the
+    source frames so the masks, the zero padding and the counts are exercised."""
+    g = zs.rng(seed)
+    feats = g.standard_normal((1, V, 32, H, W)).astype(np.float32)
+    imgs = g.uniform(0, 1, size=(1, V, 3, 4 * H, 4 * W)).astype(np.float32)
+    w2cs, intr = zs.make_cameras(V, H, W, focal=0.9 * W, spread=spread)
+    projs = []
+    for v in range(V):
+        P = np.eye(4)
+        P[:3, :4] = intr[0, v].astype(np.float64) @ w2cs[0, v, :3, :4].astype(np.float64)
+        projs.append(P)
+    ref_inv = np.linalg.inv(projs[0])
+    proj_mats = np.stack([(P @ ref_inv)[:3, :4] for P in projs]).astype(np.float32)[None]
+    proj_mats[0, 0] = np.eye(4, dtype=np.float32)[:3]
+    depth_values = np.linspace(1.5, 5.0, D, dtype=np.float32)[None]
+    return dict(feats=feats, imgs=imgs, proj_mats=proj_mats, depth_values=depth_values, pad=pad)
+
+
 # --------------------------------------------------------------- rendering cases
 def render_inputs(seed, R=32, S=16, V=3, use_mvs=True, scene_flow=False, use_mvs_dy=True,
                   lively=True):
@@ -157,6 +178,7 @@ CASES = {
     "rays_dy_motion": dict(kind="rays", seed=53, pad=2, stratified=True, torch_seed=11, scene_flow=True,
                            num_extra_samples=8),
     "rays_patches": dict(kind="rays", seed=54, pad=2, stratified=True, torch_seed=5, patch_size=4),
+    "homo_warp": dict(kind="homo_warp", seed=63, pad=3),
     "render_static_mvs": dict(kind="render", seed=31, use_mvs=True),
     "render_static_nomvs": dict(kind="render", seed=32, use_mvs=False),
     "render_static_white": dict(kind="render", seed=33, use_mvs=True, white_bkgd=True),
@@ -212,6 +234,8 @@ def build(case):
         return color_inputs(c["seed"])
     if k == "mlp":
         return mlp_inputs(c["seed"], c["variant"])
+    if k == "homo_warp":
+        return cost_inputs(c["seed"], V=c.get("V", 3), pad=c["pad"])
     if k == "rays":
         return rays_inputs(c["seed"])
     if k in ("render", "render_grad"):

@@ -111,6 +111,12 @@ def run(case, dtype=torch.float32, explicit=True):
             spec = spec_of(inp["P"], inp["Fd"], inp["sceneflow"], inp["static"], inp["use_mvs"],
                            inp["net_type"])
             out["y"] = zo.mlp_forward(state_t(inp["state"], dtype), T(inp["x"], dtype)[0], spec)
+        elif k == "homo_warp":
+            feats, imgs = T(inp["feats"], dtype)[0], T(inp["imgs"], dtype)[0]
+            H, W = feats.shape[-2:]
+            g = zo.plane_grid(T(inp["proj_mats"], dtype)[0, 1], T(inp["depth_values"], dtype)[0], H, W, inp["pad"])
+            img_lr = torch.nn.functional.interpolate(imgs, (H, W), mode="bilinear", align_corners=False)
+            out = dict(warped=zo.grid_warp(feats[1], g), img_warped=zo.grid_warp(img_lr[1], g))
         elif k == "rays":
             xs, ys = rays_pixels(c, inp)
             t = lambda a: T(a, dtype)[0]

@@ -72,6 +72,25 @@ def main():
             packed = d.net_s.packed(prec)
             t = timeit(lambda: zest_hip.mlp_fwd(desc, prec, packed, x), n=20)
             report(name, t, flops=fl, peak=peak, unit="TFLOP/s")
+        # plane-sweep cost volume at the NSFF geometry: 3 views, 72 x 128 features, pad 24, 128 planes
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import golden_cases as gc
+        inp = gc.cost_inputs(5, V=3, H=72, W=128, D=128, pad=24, spread=0.15)
+        g = lambda k: torch.from_numpy(inp[k]).to(dev)
+        feats, proj, depth = g("feats")[0], g("proj_mats")[0, 1:], g("depth_values")[0]
+        imgs_lr = torch.nn.functional.interpolate(g("imgs")[0], (72, 128), mode="bilinear", align_corners=False)
+        fcl, icl3 = zest_hip.nchw_to_nhwc(feats), zest_hip.images_to_cl(imgs_lr)
+        nvox = 128 * (72 + 48) * (128 + 48)
+        img_feat = torch.empty(41, 128, 120, 176, device=dev)
+        masks = torch.empty(3, 128, 120, 176, device=dev)
+        st = torch.cuda.current_stream().cuda_stream
+
+        def sweep():
+            rc = zest_hip.lib().zest_volume_cost_fwd(fcl.data_ptr(), icl3.data_ptr(), proj.data_ptr(), depth.data_ptr(),
+                                                      3, 32, 128, 72, 128, 24, img_feat.data_ptr(), masks.data_ptr(), st)
+            assert rc == 0
+        t = timeit(sweep, n=20)
+        report("volume_cost plane sweep (writes 44 ch x 2.7 M voxels)", t, bytes_=nvox * 44 * 4, peak=HBM_PEAK, unit="GB/s")
 
 
 if __name__ == "__main__":

@@ -22,6 +22,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
 import golden_cases as gc  # noqa: E402
 
 REF = "/root/reference"
@@ -109,6 +110,8 @@ def run_case(ref, name):
             net = ref_net(ref, inp["state"], inp["P"], inp["Fd"], inp["sceneflow"], inp["static"],
                           inp["use_mvs"], inp["net_type"])
             out["y"] = net(T(inp["x"])).numpy()[0]
+        elif k == "homo_warp":
+            out = run_homo_warp(ref.utils, inp)
         elif k == "rays":
             out = run_rays(ref.utils, c, inp)
         elif k == "render":
@@ -116,6 +119,25 @@ def run_case(ref, name):
     if k == "render_grad":
         out = run_render_grad(ref, c, inp)
     return out
+
+
+def run_homo_warp(U, inp):
+    """The sampling half of utils.homo_warp (utils.py:91-98): source view 1's feature map and its
+    resized image warped with a GIVEN grid.  The grid is an input here (computed by the oracle's
+    plane_grid): the reference's own grid construction needs kornia.create_meshgrid, which is
+    not installed, so that half stays unpinned (oracle/zest_oracle.py).  Also used by the GPU
+    test against our utils.homo_warp."""
+    from oracle import zest_oracle as zo
+    pad = inp["pad"]
+    feats, imgs = T(inp["feats"]), T(inp["imgs"])
+    H, W = feats.shape[-2:]
+    g = zo.plane_grid(T(inp["proj_mats"])[0, 1], T(inp["depth_values"])[0], H, W, pad)
+    D, Hp, Wp = g.shape[:3]
+    grid = g.view(1, D, Wp, Hp, 2)                   # the reference's shape label, memory order [D][y][x]
+    warped, _ = U.homo_warp(feats[:, 1], T(inp["proj_mats"])[:, 1], T(inp["depth_values"]), src_grid=grid, pad=pad)
+    img_lr = torch.nn.functional.interpolate(imgs[0], (H, W), mode="bilinear", align_corners=False)[1:2]
+    img_warped, _ = U.homo_warp(img_lr, T(inp["proj_mats"])[:, 1], T(inp["depth_values"]), src_grid=grid, pad=pad)
+    return dict(warped=warped[0].numpy(), img_warped=img_warped[0].numpy())
 
 
 def run_render_grad(ref, c, sc):

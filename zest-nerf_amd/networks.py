@@ -19,7 +19,8 @@ import torch.nn as nn
 
 import zest_hip
 
-__all__ = ["Embedding", "Renderer", "Renderer_linear", "MVSNeRF", "resolve_precision"]
+__all__ = ["Embedding", "Renderer", "Renderer_linear", "MVSNeRF", "resolve_precision",
+           "ActivatedBatchNorm", "ConvBnReLU", "ConvBnReLU3D", "FeatureNet", "CostRegNet", "MVSNet"]
 
 
 def resolve_precision(args=None):
@@ -184,3 +185,173 @@ class MVSNeRF(nn.Module):
             import zest_autograd
             return zest_autograd.mlp_apply(self, x)          # fp32 training path (HIP fwd + bwd)
         return self.nerf(x)
+
+
+# ------------------------------------------------------------------------------------------
+# MVS volume builder (reference networks.py:935-1238).  The convolutional
+# stacks are plain library convolutions (MIOpen through torch.nn: plumbing, not the product);
+# the plane sweep between them - homo_warp + build_volume_cost, the part that streams
+# hundreds of MB - is the HIP kernel zest_volume_cost_fwd.  The reference normalises with
+# InPlaceABN (inplace_abn, a CUDA-only extension that is not installable here): its forward is
+# batch norm followed by leaky ReLU(0.01), and its parameters are weight / bias / running_mean /
+# running_var, so ActivatedBatchNorm keeps the reference's state-dict keys and checkpoints load.
+# Parity: the plane sweep is pinned by reference-generated fixtures (tests/golden/volume_cost*,
+# homo_warp*); the convolutional stacks cannot be run in the reference without inplace_abn and
+# are "parity unpinned" (DESIGN.md 4b).
+class ActivatedBatchNorm(nn.BatchNorm2d):
+    """InPlaceABN substitute: BatchNorm (any spatial rank) + leaky ReLU(0.01)."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, activation="leaky_relu",
+                 activation_param=0.01):
+        super().__init__(num_features, eps=eps, momentum=momentum, affine=affine)
+        if activation not in ("leaky_relu", "identity"):
+            raise NotImplementedError("ActivatedBatchNorm: activation %r" % (activation,))
+        self.activation, self.activation_param = activation, activation_param
+
+    def _check_input_dim(self, input):
+        if input.dim() < 3:
+            raise ValueError("expected at least 3D input (got %dD)" % input.dim())
+
+    def forward(self, x):
+        y = super().forward(x)
+        return torch.nn.functional.leaky_relu(y, self.activation_param) if self.activation == "leaky_relu" else y
+
+
+class ConvBnReLU(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, pad=1,
+                 norm_act=ActivatedBatchNorm):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=pad, bias=False)
+        self.bn = norm_act(out_channels)
+
+    def forward(self, x):
+        return self.bn(self.conv(x))
+
+
+class ConvBnReLU3D(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, pad=1,
+                 norm_act=ActivatedBatchNorm):
+        super().__init__()
+        self.conv = nn.Conv3d(in_channels, out_channels, kernel_size, stride=stride, padding=pad, bias=False)
+        self.bn = norm_act(out_channels)
+
+    def forward(self, x):
+        return self.bn(self.conv(x))
+
+
+class FeatureNet(nn.Module):
+    """Three-level feature pyramid; the top level (32 channels at 1/4 resolution) feeds the
+    plane sweep (reference networks.py:962-1001)."""
+
+    def __init__(self, norm_act=ActivatedBatchNorm):
+        super().__init__()
+        self.conv0 = nn.Sequential(ConvBnReLU(3, 8, 3, 1, 1, norm_act=norm_act),
+                                   ConvBnReLU(8, 8, 3, 1, 1, norm_act=norm_act))
+        self.conv1 = nn.Sequential(ConvBnReLU(8, 16, 5, 2, 2, norm_act=norm_act),
+                                   ConvBnReLU(16, 16, 3, 1, 1, norm_act=norm_act),
+                                   ConvBnReLU(16, 16, 3, 1, 1, norm_act=norm_act))
+        self.conv2 = nn.Sequential(ConvBnReLU(16, 32, 5, 2, 2, norm_act=norm_act),
+                                   ConvBnReLU(32, 32, 3, 1, 1, norm_act=norm_act),
+                                   ConvBnReLU(32, 32, 3, 1, 1, norm_act=norm_act))
+        self.toplayer = nn.Conv2d(32, 32, 1)
+
+    def _upsample_add(self, x, y):
+        return torch.nn.functional.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True) + y
+
+    def forward(self, x):
+        activ_maps = []
+        x = self.conv0(x)
+        activ_maps.append(x)
+        x = self.conv1(x)
+        activ_maps.append(x)
+        x = self.conv2(x)
+        activ_maps.append(x)
+        x = self.toplayer(x)
+        activ_maps.append(x)
+        return x, activ_maps
+
+
+class CostRegNet(nn.Module):
+    """3-D U-Net: cost volume -> 8-channel neural encoding volume (reference networks.py:1003-1059)."""
+
+    def __init__(self, in_channels, norm_act=ActivatedBatchNorm):
+        super().__init__()
+        self.conv0 = ConvBnReLU3D(in_channels, 8, norm_act=norm_act)
+        self.conv1 = ConvBnReLU3D(8, 16, stride=2, norm_act=norm_act)
+        self.conv2 = ConvBnReLU3D(16, 16, norm_act=norm_act)
+        self.conv3 = ConvBnReLU3D(16, 32, stride=2, norm_act=norm_act)
+        self.conv4 = ConvBnReLU3D(32, 32, norm_act=norm_act)
+        self.conv5 = ConvBnReLU3D(32, 64, stride=2, norm_act=norm_act)
+        self.conv6 = ConvBnReLU3D(64, 64, norm_act=norm_act)
+        up = lambda i, o: nn.Sequential(
+            nn.ConvTranspose3d(i, o, 3, padding=1, output_padding=1, stride=2, bias=False), norm_act(o))
+        self.conv7, self.conv9, self.conv11 = up(64, 32), up(32, 16), up(16, 8)
+
+    def forward(self, x):
+        activ_maps = []
+        conv0 = self.conv0(x)
+        conv2 = self.conv2(self.conv1(conv0))
+        conv4 = self.conv4(self.conv3(conv2))
+        activ_maps += [conv0, conv2, conv4]
+        x = self.conv6(self.conv5(conv4))
+        activ_maps.append(x)
+        x = conv4 + self.conv7(x)
+        activ_maps.append(x)
+        x = conv2 + self.conv9(x)
+        activ_maps.append(x)
+        x = conv0 + self.conv11(x)
+        activ_maps.append(x)
+        return x, activ_maps
+
+
+class MVSNet(nn.Module):
+    """Encoding-volume builder: 2-D features -> plane-sweep variance cost volume (HIP) -> 3-D
+    regularisation.  Constructor, attribute names and state-dict keys follow the reference
+    (networks.py:1061-1238)."""
+
+    def __init__(self, num_groups=1, norm_act=ActivatedBatchNorm, levels=1):
+        super().__init__()
+        self.levels = levels
+        self.n_depths = [128, 32, 8]
+        self.G = num_groups
+        self.feature = FeatureNet()
+        self.chunk = 1024
+        self.cost_reg_2 = CostRegNet(32 + 9, norm_act)
+
+    def build_volume_cost(self, imgs, feats, proj_mats, depth_values, pad=0):
+        """imgs [1,V,3,Hi,Wi]; feats [1,V,32,H,W]; proj_mats [1,V,3,4]; depth_values [1,D]
+        -> (img_feat [1,3V+32,D,H+2pad,W+2pad], in_masks [1,V,D,H+2pad,W+2pad]).  One HIP launch
+        (zest_volume_cost_fwd); forward only."""
+        B, V, C, H, W = feats.shape
+        if B != 1:
+            raise RuntimeError("build_volume_cost: batch must be 1 (the reference assumes it too)")
+        if torch.is_grad_enabled() and (feats.requires_grad or imgs.requires_grad):
+            raise NotImplementedError("build_volume_cost: the HIP plane sweep has no backward; run the "
+                                      "volume builder under torch.no_grad() (inference / frozen MVSNet)")
+        imgs_lr = torch.nn.functional.interpolate(imgs.reshape(B * V, *imgs.shape[2:]), (H, W), mode="bilinear",
+                                                  align_corners=False)
+        depth = depth_values.reshape(depth_values.shape[0], -1)[0]
+        img_feat, masks = zest_hip.volume_cost(feats[0], imgs_lr, proj_mats[0, 1:], depth, pad)
+        return img_feat[None], masks[None]
+
+    def forward(self, imgs, proj_mats, near_far, pad=0, return_color=False, lindisp=False,
+                vis_test=False, test_dir=None):
+        if vis_test:
+            raise NotImplementedError("MVSNet.forward: vis_test dumps are a debugging aid of the reference")
+        B, V, _, H, W = imgs.shape
+        feats, _ = self.feature(imgs.reshape(B * V, 3, H, W))
+        feats = feats.view(B, V, *feats.shape[1:])
+        D = 128
+        t_vals = torch.linspace(0., 1., steps=D, device=imgs.device, dtype=imgs.dtype)
+        near, far = near_far
+        if not lindisp:
+            depth_values = near * (1. - t_vals) + far * t_vals
+        else:
+            depth_values = 1. / (1. / near * (1. - t_vals) + 1. / far * t_vals)
+        depth_values = depth_values.unsqueeze(0)
+        cost_vol, in_masks = self.build_volume_cost(imgs, feats, proj_mats, depth_values, pad=pad)
+        if return_color:
+            feats = torch.cat((cost_vol[:, :V * 3].view(B, V, 3, *cost_vol.shape[2:]), in_masks.unsqueeze(2)), dim=2)
+        volume_feat, _ = self.cost_reg_2(cost_vol)
+        volume_feat = volume_feat.reshape(1, -1, *volume_feat.shape[2:])
+        return volume_feat, feats, depth_values

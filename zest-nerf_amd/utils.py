@@ -12,7 +12,7 @@ import torch
 
 import zest_hip
 
-__all__ = ["index_point_feature", "build_color_volume", "volume_channels_last",
+__all__ = ["homo_warp", "index_point_feature", "build_color_volume", "volume_channels_last",
            "images_channels_last", "get_ndc_coordinate", "get_rays_mvs", "build_rays_base",
            "build_rays", "build_rays_dy"]
 
@@ -68,6 +68,29 @@ def build_color_volume(point_samples, poses, imgs, img_feat=None, downscale=1.0,
         return out
     V = icl.shape[0]
     return out.view(*out.shape[:-1], V, 4)[..., :3].reshape(*out.shape[:-1], 3 * V)
+
+
+# ---------------------------------------------------------------------------- plane sweep
+def homo_warp(src_feat, proj_mat, depth_values, src_grid=None, pad=0):
+    """Warp a source feature map onto the fronto-parallel planes of the reference view
+    (reference utils.py:49-99).  src_feat [1,C,H,W]; proj_mat [1,3,4] =
+    src_proj @ ref_proj_inv; depth_values [1,D].  -> (warped [1,C,D,H+2pad,W+2pad],
+    src_grid [1,D,W+2pad,H+2pad,2]: the reference's shape label for the normalised sampling
+    positions, memory order [D][y][x]).  With src_grid given it is reused, as the reference does
+    for the colour images.  Forward only: the volume builder is run without autograd here."""
+    if src_feat.shape[0] != 1:
+        raise RuntimeError("homo_warp: batch must be 1 (the reference never uses more)")
+    if torch.is_grad_enabled() and (src_feat.requires_grad or (proj_mat is not None and proj_mat.requires_grad)):
+        raise NotImplementedError("homo_warp: the HIP plane sweep has no backward; run the volume "
+                                  "builder under torch.no_grad() (inference / frozen MVSNet)")
+    if src_grid is None:
+        depth = depth_values.reshape(depth_values.shape[0], -1)[0]
+        warped, grid = zest_hip.homo_warp(src_feat[0], proj_mat[0], depth, None, pad)
+    else:
+        D, Wp, Hp = src_grid.shape[1:4]
+        warped, grid = zest_hip.homo_warp(src_feat[0], grid=src_grid.reshape(D, Hp, Wp, 2), pad=pad)
+    D, Hp, Wp = grid.shape[:3]
+    return warped[None], grid.view(1, D, Wp, Hp, 2)
 
 
 # ---------------------------------------------------------------------------- ray sampling

@@ -53,6 +53,9 @@ _SIGS = {
     "zest_embed_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "zest_volume_to_cl": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "zest_images_to_cl": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "zest_nchw_to_nhwc": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "zest_volume_cost_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "zest_homo_warp_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "zest_volume_lookup_fwd": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     "zest_color_lookup_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "zest_encode_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp, _i, _i, _i, _vp, _i, _i, _i,
@@ -188,6 +191,54 @@ def volume_to_cl(vol):
     out = torch.empty(D, H, W, 8, device=vol.device, dtype=torch.float32)
     _check(lib().zest_volume_to_cl(_ptr(vol), D, H, W, _ptr(out), _stream(vol)), "zest_volume_to_cl")
     return out
+
+
+def nchw_to_nhwc(x):
+    """[N,C,H,W] -> [N,H,W,C]."""
+    x = _dev(x, "x")
+    N, Cc, H, W = x.shape
+    out = torch.empty(N, H, W, Cc, device=x.device, dtype=torch.float32)
+    _check(lib().zest_nchw_to_nhwc(_ptr(x), N, Cc, H, W, _ptr(out), _stream(x)), "zest_nchw_to_nhwc")
+    return out
+
+
+def volume_cost(feats, imgs_lr, proj, depth, pad=0):
+    """Plane-sweep cost volume.  feats [V,32,H,W]; imgs_lr [V,3,H,W] (at feature resolution);
+    proj [V-1,3,4]; depth [D] -> img_feat [3V+32, D, H+2pad, W+2pad], in_masks [V, D, Hp, Wp]."""
+    feats, imgs_lr = _dev(feats, "feats"), _dev(imgs_lr, "imgs")
+    proj, depth = _dev(proj, "proj_mats"), _dev(depth, "depth_values")
+    V, Cc, H, W = feats.shape
+    if tuple(imgs_lr.shape) != (V, 3, H, W) or tuple(proj.shape) != (V - 1, 3, 4) or depth.dim() != 1:
+        raise RuntimeError("zest_hip.volume_cost: feats %s imgs %s proj %s depth %s"
+                           % (tuple(feats.shape), tuple(imgs_lr.shape), tuple(proj.shape), tuple(depth.shape)))
+    D, Hp, Wp = depth.shape[0], H + 2 * pad, W + 2 * pad
+    fcl, icl = nchw_to_nhwc(feats), images_to_cl(imgs_lr)
+    img_feat = torch.empty(3 * V + Cc, D, Hp, Wp, device=feats.device, dtype=torch.float32)
+    masks = torch.empty(V, D, Hp, Wp, device=feats.device, dtype=torch.float32)
+    _check(lib().zest_volume_cost_fwd(_ptr(fcl), _ptr(icl), _ptr(proj), _ptr(depth), V, Cc, D, H, W, pad,
+                                      _ptr(img_feat), _ptr(masks), _stream(feats)), "zest_volume_cost_fwd")
+    return img_feat, masks
+
+
+def homo_warp(src, proj=None, depth=None, grid=None, pad=0):
+    """src [C,H,W]; proj [3,4] + depth [D], or grid [D,Hp,Wp,2] -> warped [C,D,Hp,Wp], grid."""
+    src = _dev(src, "src_feat")
+    Cc, H, W = src.shape
+    if grid is None:
+        proj, depth = _dev(proj, "proj_mat"), _dev(depth, "depth_values")
+        D, Hp, Wp = depth.shape[0], H + 2 * pad, W + 2 * pad
+        grid_out = torch.empty(D, Hp, Wp, 2, device=src.device, dtype=torch.float32)
+        gin = None
+    else:
+        gin = _dev(grid, "src_grid")
+        D, Hp, Wp = gin.shape[:3]
+        grid_out = gin
+    warped = torch.empty(Cc, D, Hp, Wp, device=src.device, dtype=torch.float32)
+    _check(lib().zest_homo_warp_fwd(_ptr(src), _ptr(proj) if gin is None else None,
+                                    _ptr(depth) if gin is None else None, _ptr(gin) if gin is not None else None,
+                                    Cc, D, H, W, Hp, Wp, pad, _ptr(warped),
+                                    _ptr(grid_out) if gin is None else None, _stream(src)), "zest_homo_warp_fwd")
+    return warped, grid_out
 
 
 def images_to_cl(imgs):

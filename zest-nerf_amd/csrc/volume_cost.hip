@@ -3,12 +3,12 @@
 // Replaces MVSNet.build_volume_cost (reference networks.py:1077-1140) and utils.homo_warp
 // (utils.py:49-99).  The reference materialises, per source view, a [C,D,H,W] warped feature
 // volume, its square, a warped image volume and a sampling grid, and reduces them with a dozen
-// elementwise passes.  Here one thread owns one voxel (d, y, x) of the padded reference grid:
-// it projects the voxel into every source view (homography at the plane's depth), takes the
-// four bilinear taps of the 32-channel feature map (channels-last: 128 contiguous bytes per
-// tap) and of the image, keeps the running sum / sum of squares / in-frame count in registers
-// and writes the 3 V image channels, the 32 variance channels and the V masks once.  Bound: the
-// HBM write of the output (41 x D x Hp x Wp floats); the source maps are a few MB and stay in L2.
+// elementwise passes.  Here every voxel (d, y, x) of the padded reference grid is projected into
+// every source view once (homography at the plane's depth), the four bilinear taps of the
+// 32-channel feature map (channels-last: 128 contiguous bytes per tap) and of the image are
+// taken, the running sum / sum of squares / in-frame count stay in registers, and the 3 V image
+// channels, the 32 variance channels and the V masks are written once.  Bound: the HBM write of
+// the output (41 x D x Hp x Wp floats); the source maps are a few MB and stay in L2.
 #include "zest_common.cuh"
 #include "../../include/zest_render.h"
 
@@ -65,72 +65,127 @@ __global__ void nchw_to_nhwc_kernel(const float *__restrict__ in, int N, int C, 
 
 // feats_cl [V,H,W,32], imgs_cl [V,H,W,4] (rgb + pad), proj [V-1,3,4], depth [D]
 // img_feat [3V + 32, D, Hp, Wp], in_masks [V, D, Hp, Wp]
-__global__ __launch_bounds__(kThreads) void volume_cost_kernel(
+//
+// A workgroup is one wave and owns 64 consecutive voxels.  Phase 1, one lane per voxel: the
+// homographies, bilinear weights and tap offsets are computed once per voxel and left in LDS.  Phase 2 walks the voxels 8 at a time with lane = (voxel of the octet, channel quad
+// q): a bilinear tap of a voxel is then ONE 128-byte line read by 8 neighbouring lanes, where a
+// lane-per-voxel gather touches 64 lines per load instruction and uses 16 bytes of each.  The
+// 4V + 32 output values of the 64 voxels are transposed through LDS (row stride 66 floats: the
+// quad-strided writes fall on distinct banks up to a free 2-way) so every output plane
+// receives 256 contiguous bytes.  Geometry and transpose tile are separate LDS arrays, so the
+// eight octets are independent for the compiler and their loads overlap.
+constexpr int kRowStride = 66;
+constexpr int kMaxViews = 8;
+
+template <int VT>                   // VT > 0: compile-time view count (loops unroll)
+__global__ __launch_bounds__(64) void volume_cost_kernel(
     const float4 *__restrict__ feats, const float4 *__restrict__ imgs, const float *__restrict__ proj,
-    const float *__restrict__ depth, int V, int D, int H, int W, int pad, float *__restrict__ img_feat,
+    const float *__restrict__ depth, int V_rt, int D, int H, int W, int pad, float *__restrict__ img_feat,
     float *__restrict__ in_masks) {
+    const int V = VT > 0 ? VT : V_rt;
+    constexpr int VM = VT > 0 ? VT : kMaxViews;
+    __shared__ float tile[(4 * VM + kC) * kRowStride];         // [rows][kRowStride]
+    __shared__ int4 toff[(VM - 1) * 64];                       // bilinear tap offsets / weights per source view
+    __shared__ float4 tw[(VM - 1) * 64];
+    __shared__ float4 vox[64];          // ref pixel offset (-1: ring, -2: past the end), 1/count, in-frame bit mask
     const int Hp = H + 2 * pad, Wp = W + 2 * pad;
     const long long nvox = (long long)D * Hp * Wp;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= nvox) return;
-    const int x = (int)(idx % Wp), y = (int)((idx / Wp) % Hp), d = (int)(idx / ((long long)Wp * Hp));
-    const int xr = x - pad, yr = y - pad;
-    const bool inside = (unsigned)xr < (unsigned)W && (unsigned)yr < (unsigned)H;
-    const float dep = depth[d];
-    float sum[kC], sq[kC];
-    {   // reference view: its own feature map, zero in the padding ring
-        const float4 *f = feats + (size_t)(inside ? yr * W + xr : 0) * (kC / 4);
+    const int lane = threadIdx.x, vsub = lane >> 3, q = lane & 7;
+    const long long base = (long long)blockIdx.x * 64;
+    {   // ---- phase 1: lane = voxel
+        const long long idx = base + lane;
+        const bool live = idx < nvox;
+        // 32-bit index arithmetic (the host checks nvox < 2^31)
+        const unsigned ic = (unsigned)(live ? idx : nvox - 1);
+        const unsigned row = ic / (unsigned)Wp;
+        const int x = (int)(ic - row * (unsigned)Wp), d = (int)(row / (unsigned)Hp), y = (int)(row - (unsigned)d * (unsigned)Hp);
+        const int xr = x - pad, yr = y - pad;
+        const bool inside = (unsigned)xr < (unsigned)W && (unsigned)yr < (unsigned)H;
+        const float dep = depth[d];
+        float count = 1.0f;
+        int in_frame = 1;
 #pragma unroll
-        for (int q = 0; q < kC / 4; q++) {
-            const float4 v = inside ? f[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-            sum[4 * q] = v.x, sum[4 * q + 1] = v.y, sum[4 * q + 2] = v.z, sum[4 * q + 3] = v.w;
+        for (int i = 1; i < V; i++) {
+            float gx, gy;
+            project(proj + 12 * (i - 1), (float)xr, (float)yr, dep, H, W, gx, gy);
+            const bool m = gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f;
+            count += m ? 1.0f : 0.0f, in_frame |= m ? (1 << i) : 0;
+            const Tap4 t = taps(gx, gy, H, W);
+            toff[(i - 1) * 64 + lane] = make_int4(t.off[0], t.off[1], t.off[2], t.off[3]);
+            tw[(i - 1) * 64 + lane] = make_float4(t.w[0], t.w[1], t.w[2], t.w[3]);
+        }
+        vox[lane] = make_float4(__int_as_float(live ? (inside ? yr * W + xr : -1) : -2), 1.0f / count,
+                                __int_as_float(in_frame), 0.0f);
+    }
+    __syncthreads();
+    // ---- phase 2: lane = (voxel of the octet, channel quad)
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const int v = it * 8 + vsub;
+        const float4 g = vox[v];
+        const int ref_off = __float_as_int(g.x);
+        if (ref_off == -2) continue;                           // past the end of the volume
+        // reference view: its own feature map, zero in the padding ring
+        float4 sum = ref_off >= 0 ? feats[(size_t)ref_off * (kC / 4) + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 sq = make_float4(sum.x * sum.x, sum.y * sum.y, sum.z * sum.z, sum.w * sum.w);
+        if (q == 0) {
+            // the reference leaves channels 0-2 of the padding ring uninitialised (torch.empty); 0 here
+            const float4 c0 = ref_off >= 0 ? imgs[ref_off] : make_float4(0.f, 0.f, 0.f, 0.f);
+            tile[0 * kRowStride + v] = c0.x, tile[1 * kRowStride + v] = c0.y, tile[2 * kRowStride + v] = c0.z;
+            tile[(3 * V + kC) * kRowStride + v] = 1.0f;
         }
 #pragma unroll
-        for (int c = 0; c < kC; c++) sq[c] = sum[c] * sum[c];
-        // the reference leaves channels 0-2 of the padding ring uninitialised (torch.empty); 0 here
-        const float4 c0 = inside ? imgs[(size_t)yr * W + xr] : make_float4(0.f, 0.f, 0.f, 0.f);
-        img_feat[0 * nvox + idx] = c0.x, img_feat[1 * nvox + idx] = c0.y, img_feat[2 * nvox + idx] = c0.z;
-        in_masks[idx] = 1.0f;
-    }
-    float count = 1.0f;
-    for (int i = 1; i < V; i++) {
-        float gx, gy;
-        project(proj + 12 * (i - 1), (float)xr, (float)yr, dep, H, W, gx, gy);
-        const float m = (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.0f : 0.0f;
-        in_masks[(size_t)i * nvox + idx] = m;
-        count += m;
-        const Tap4 t = taps(gx, gy, H, W);
-        const float4 *f = feats + (size_t)i * H * W * (kC / 4);
-#pragma unroll
-        for (int q = 0; q < kC / 4; q++) {
+        for (int i = 1; i < V; i++) {
+            const int4 o4 = toff[(i - 1) * 64 + v];
+            const float4 w4 = tw[(i - 1) * 64 + v];
+            Tap4 t;
+            t.off[0] = o4.x, t.off[1] = o4.y, t.off[2] = o4.z, t.off[3] = o4.w;
+            t.w[0] = w4.x, t.w[1] = w4.y, t.w[2] = w4.z, t.w[3] = w4.w;
+            const float4 *f = feats + (size_t)i * H * W * (kC / 4);
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                const float4 v = f[(size_t)t.off[c] * (kC / 4) + q];
-                a.x = fmaf(t.w[c], v.x, a.x), a.y = fmaf(t.w[c], v.y, a.y);
-                a.z = fmaf(t.w[c], v.z, a.z), a.w = fmaf(t.w[c], v.w, a.w);
+#ifdef ZEST_EXPERIMENT_NO_GATHER       // timing experiment only
+                const float4 tv = make_float4(t.w[c], 1.f, 2.f, 3.f);
+#else
+                const float4 tv = f[(size_t)t.off[c] * (kC / 4) + q];
+#endif
+                a.x = fmaf(t.w[c], tv.x, a.x), a.y = fmaf(t.w[c], tv.y, a.y);
+                a.z = fmaf(t.w[c], tv.z, a.z), a.w = fmaf(t.w[c], tv.w, a.w);
             }
-            sum[4 * q] += a.x, sum[4 * q + 1] += a.y, sum[4 * q + 2] += a.z, sum[4 * q + 3] += a.w;
-            sq[4 * q] = fmaf(a.x, a.x, sq[4 * q]), sq[4 * q + 1] = fmaf(a.y, a.y, sq[4 * q + 1]);
-            sq[4 * q + 2] = fmaf(a.z, a.z, sq[4 * q + 2]), sq[4 * q + 3] = fmaf(a.w, a.w, sq[4 * q + 3]);
-        }
-        const float4 *im = imgs + (size_t)i * H * W;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            sum.x += a.x, sum.y += a.y, sum.z += a.z, sum.w += a.w;
+            sq.x = fmaf(a.x, a.x, sq.x), sq.y = fmaf(a.y, a.y, sq.y), sq.z = fmaf(a.z, a.z, sq.z), sq.w = fmaf(a.w, a.w, sq.w);
+            if (q == (i & 7)) {                                // the image taps: one lane of the octet per view
+                const float4 *im = imgs + (size_t)i * H * W;
+                float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const float4 v = im[t.off[c]];
-            a.x = fmaf(t.w[c], v.x, a.x), a.y = fmaf(t.w[c], v.y, a.y), a.z = fmaf(t.w[c], v.z, a.z);
+                for (int c = 0; c < 4; c++) {
+                    const float4 tv = im[t.off[c]];
+                    b.x = fmaf(t.w[c], tv.x, b.x), b.y = fmaf(t.w[c], tv.y, b.y), b.z = fmaf(t.w[c], tv.z, b.z);
+                }
+                tile[(3 * i) * kRowStride + v] = b.x, tile[(3 * i + 1) * kRowStride + v] = b.y;
+                tile[(3 * i + 2) * kRowStride + v] = b.z;
+                tile[(3 * V + kC + i) * kRowStride + v] = ((__float_as_int(g.z) >> i) & 1) ? 1.0f : 0.0f;
+            }
         }
-        img_feat[(size_t)(3 * i) * nvox + idx] = a.x;
-        img_feat[(size_t)(3 * i + 1) * nvox + idx] = a.y;
-        img_feat[(size_t)(3 * i + 2) * nvox + idx] = a.z;
+        const float inv = g.y;
+        float *o = tile + (size_t)(3 * V + 4 * q) * kRowStride + v;
+        float mean = sum.x * inv;
+        o[0] = sq.x * inv - mean * mean;
+        mean = sum.y * inv, o[kRowStride] = sq.y * inv - mean * mean;
+        mean = sum.z * inv, o[2 * kRowStride] = sq.z * inv - mean * mean;
+        mean = sum.w * inv, o[3 * kRowStride] = sq.w * inv - mean * mean;
     }
-    const float inv = 1.0f / count;
-#pragma unroll
-    for (int c = 0; c < kC; c++) {
-        const float mean = sum[c] * inv;
-        img_feat[(size_t)(3 * V + c) * nvox + idx] = sq[c] * inv - mean * mean;
+    __syncthreads();
+    const long long idx = base + lane;
+    if (idx >= nvox) return;
+    for (int r = 0; r < 3 * V + kC; r++) {
+#ifdef ZEST_EXPERIMENT_NO_WRITE        // timing experiment only
+        if (tile[r * kRowStride + lane] == 123456.0f)
+#endif
+        img_feat[(size_t)r * nvox + idx] = tile[r * kRowStride + lane];
     }
+    for (int i = 0; i < V; i++) in_masks[(size_t)i * nvox + idx] = tile[(3 * V + kC + i) * kRowStride + lane];
 }
 
 // src [C,H,W]; grid_in (optional) [D,Hp,Wp,2] normalised positions to reuse; outputs
@@ -146,7 +201,8 @@ __global__ __launch_bounds__(kThreads) void homo_warp_kernel(
     if (grid_in) {
         gx = grid_in[2 * idx], gy = grid_in[2 * idx + 1];
     } else {
-        const int x = (int)(idx % Wp), y = (int)((idx / Wp) % Hp), d = (int)(idx / ((long long)Wp * Hp));
+        const unsigned row = (unsigned)idx / (unsigned)Wp;
+        const int x = (int)((unsigned)idx - row * (unsigned)Wp), d = (int)(row / (unsigned)Hp), y = (int)(row - (unsigned)d * (unsigned)Hp);
         project(proj, (float)(x - pad), (float)(y - pad), depth[d], H, W, gx, gy);
         grid_out[2 * idx] = gx, grid_out[2 * idx + 1] = gy;
     }
@@ -180,10 +236,17 @@ extern "C" int zest_volume_cost_fwd(const float *feats_cl, const float *imgs_cl,
                        aligned16(imgs_cl), "zest_volume_cost_fwd: bad pointer");
     ZEST_CHECK_ARG(C == kC, "zest_volume_cost_fwd: %d feature channels (the FeatureNet top level has %d)", C, kC);
     ZEST_CHECK_ARG(V >= 2 && D >= 1 && H >= 2 && W >= 2 && pad >= 0, "zest_volume_cost_fwd: bad shape");
+    ZEST_CHECK_ARG(V <= kMaxViews, "zest_volume_cost_fwd: at most %d views (LDS transpose tile), got %d", kMaxViews, V);
     const long long nvox = (long long)D * (H + 2 * pad) * (W + 2 * pad);
-    hipLaunchKernelGGL(volume_cost_kernel, dim3(zest_div_up(nvox, kThreads)), dim3(kThreads), 0,
-                       (hipStream_t)stream, (const float4 *)feats_cl, (const float4 *)imgs_cl, proj, depth,
-                       V, D, H, W, pad, img_feat, in_masks);
+    ZEST_CHECK_ARG(nvox < (1ll << 31), "zest_volume_cost_fwd: %lld voxels exceed the 32-bit index range", nvox);
+#define ZEST_SWEEP(VT)                                                                               \
+    hipLaunchKernelGGL(volume_cost_kernel<VT>, dim3(zest_div_up(nvox, 64)), dim3(64), 0,                 \
+                       (hipStream_t)stream, (const float4 *)feats_cl, (const float4 *)imgs_cl, proj, depth, \
+                       V, D, H, W, pad, img_feat, in_masks)
+    if (V == 3) ZEST_SWEEP(3);          // the shipped configurations: reference + 2 source views
+    else if (V == 4) ZEST_SWEEP(4);
+    else ZEST_SWEEP(0);
+#undef ZEST_SWEEP
     ZEST_RETURN_LAUNCH("zest_volume_cost_fwd");
 }
 
@@ -198,6 +261,7 @@ extern "C" int zest_homo_warp_fwd(const float *src, const float *proj, const flo
     ZEST_CHECK_ARG(grid_in || (Hp == H + 2 * pad && Wp == W + 2 * pad),
                    "zest_homo_warp_fwd: padded grid %dx%d does not match %dx%d + 2*%d", Hp, Wp, H, W, pad);
     const long long nvox = (long long)D * Hp * Wp;
+    ZEST_CHECK_ARG(nvox < (1ll << 31), "zest_homo_warp_fwd: %lld voxels exceed the 32-bit index range", nvox);
     hipLaunchKernelGGL(homo_warp_kernel, dim3(zest_div_up(nvox, kThreads)), dim3(kThreads), 0,
                        (hipStream_t)stream, src, proj, depth, grid_in, C, D, H, W, Hp, Wp, pad, warped, grid_out);
     ZEST_RETURN_LAUNCH("zest_homo_warp_fwd");

@@ -128,6 +128,22 @@ int zest_homo_warp_fwd(const float *src, const float *proj, const float *depth, 
                        int C, int D, int H, int W, int Hp, int Wp, int pad, float *warped,
                        float *grid_out, void *stream);
 
+/* ---- loss-side reductions over the samples of a ray -------------------
+ * zest_distortion_fwd: distortion_loss (reference losses.py:53-87) per ray.  weights [R,S];
+ *   t_vals [t_rows,S] with t_rows 1 or R.  loss_ray [R] (the reference returns their sum);
+ *   grad_w [R,S] or NULL receives d loss_ray / d weights (t_vals carry no gradient).
+ * zest_project_rays_fwd/bwd: projection_from_ndc (reference utils.py:507-539).  weights [R,S],
+ *   pts [R,S,3] NDC points, w2c [>=12] row-major rows of (R | t), image size H x W, focal.
+ *   -> out [R,2] pixel positions; bwd: grad_out [R,2] -> d_weights [R,S], d_pts [R,S,3]
+ *   (either may be NULL). */
+int zest_distortion_fwd(const float *weights, const float *t_vals, int t_rows, int R, int S,
+                        float *loss_ray, float *grad_w, void *stream);
+int zest_project_rays_fwd(const float *weights, const float *pts, const float *w2c, int H, int W,
+                          float focal, int R, int S, float *out, void *stream);
+int zest_project_rays_bwd(const float *weights, const float *pts, const float *w2c, int H, int W,
+                          float focal, const float *grad_out, int R, int S, float *d_weights,
+                          float *d_pts, void *stream);
+
 /* Trilinear lookup, zero padding, align_corners: index_point_feature
  * (reference utils.py:433-459).  vol_cl [D,H,W,8]; ndc [M,3] -> out [M,8]. */
 int zest_volume_lookup_fwd(const float *vol_cl, int D, int H, int W, const float *ndc, int M,

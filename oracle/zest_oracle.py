@@ -453,6 +453,33 @@ def volume_cost(imgs, feats, proj_mats, depth, pad=0):
     return img_feat, masks
 
 
+# ------------------------------------------------ loss-side reductions (8(f) row 4)
+def distortion_loss(ray_weights, t_vals):
+    """ray_weights [R,S], t_vals [1,S] or [R,S] -> scalar.
+
+    Restates distortion_loss, /root/reference/losses.py:53-87 (pairs over the S-1 intervals)."""
+    w = ray_weights[..., :-1]
+    mids = 0.5 * (t_vals[..., :-1] + t_vals[..., 1:])
+    pair = (w[..., :, None] * w[..., None, :]) * (mids[..., :, None] - mids[..., None, :]).abs()
+    inter = (1.0 / 3.0) * (w * w * (t_vals[..., 1:] - t_vals[..., :-1])).sum(-1)
+    return (0.5 * pair.sum((-1, -2)) + inter).sum()
+
+
+def projection_from_ndc(w2c, H, W, f, weights, pts):
+    """weights [R,S], pts [R,S,3], w2c [4,4] -> [R,2].
+
+    Restates projection_from_ndc with NDC2Euclidean, se3_transform_points and
+    perspective_projection, /root/reference/utils.py:507-539."""
+    p = (weights[..., None] * pts).sum(-2)
+    ze = 2.0 / (p[..., 2:3].clamp(-1.0, 0.99) - 1.0)
+    xe = -p[..., 0:1] * ze * W / (2.0 * f)
+    ye = -p[..., 1:2] * ze * H / (2.0 * f)
+    e = torch.cat([xe, ye, ze], -1)
+    loc = e @ w2c[:3, :3].T + w2c[:3, 3]
+    return torch.cat([loc[..., 0:1] * f / -loc[..., 2:3] + W / 2.0,
+                      -loc[..., 1:2] * f / -loc[..., 2:3] + H / 2.0], -1)
+
+
 def num_threads():
     return torch.get_num_threads()
 

@@ -102,6 +102,23 @@ def mlp_inputs(seed, variant, M=64):
     return dict(state=state, x=x, P=P, Fd=Fd, sceneflow=sf, static=st, use_mvs=mvs, net_type=nt)
 
 
+# --------------------------------------------------------------- loss-side cases
+def loss_inputs(seed, R=12, S=40, jitter=False):
+    """Compositing-like weights, sorted normalised sample positions, NDC points around the
+    frustum (some beyond the clamp of NDC2Euclidean) and a neighbour camera."""
+    g = zs.rng(seed)
+    w = g.uniform(0, 1, size=(1, R, S)).astype(np.float32)
+    w = (w / w.sum(-1, keepdims=True) * g.uniform(0.3, 1.0, size=(1, R, 1))).astype(np.float32)
+    t = np.linspace(0, 1, S, dtype=np.float32)[None]
+    if jitter:
+        t = np.sort(np.clip(t + g.uniform(-0.4, 0.4, size=(R, S)).astype(np.float32) / S, 0, 1), -1)
+    pts = g.uniform(-1.0, 1.0, size=(1, R, S, 3)).astype(np.float32)
+    pts[..., 2] = g.uniform(-1.2, 1.05, size=(1, R, S)).astype(np.float32)
+    w2cs, _ = zs.make_cameras(3, 24, 32, focal=30.0)
+    gw = g.standard_normal((1, R, 2)).astype(np.float32)
+    return dict(weights=w, t_vals=t.astype(np.float32), pts=pts, w2c=w2cs[:, 2], H=24, W=32, f=30.0, gw=gw)
+
+
 # --------------------------------------------------------------- plane-sweep cases
 def cost_inputs(seed, V=3, H=18, W=24, D=6, pad=2, spread=0.35):
     """Feature maps, images and homographies src_proj @ ref_proj_inv at feature resolution for
@@ -179,6 +196,7 @@ CASES = {
                            num_extra_samples=8),
     "rays_patches": dict(kind="rays", seed=54, pad=2, stratified=True, torch_seed=5, patch_size=4),
     "homo_warp": dict(kind="homo_warp", seed=63, pad=3),
+    "loss_side": dict(kind="loss_side", seed=71),
     "render_static_mvs": dict(kind="render", seed=31, use_mvs=True),
     "render_static_nomvs": dict(kind="render", seed=32, use_mvs=False),
     "render_static_white": dict(kind="render", seed=33, use_mvs=True, white_bkgd=True),
@@ -234,6 +252,8 @@ def build(case):
         return color_inputs(c["seed"])
     if k == "mlp":
         return mlp_inputs(c["seed"], c["variant"])
+    if k == "loss_side":
+        return loss_inputs(c["seed"], jitter=c.get("jitter", False))
     if k == "homo_warp":
         return cost_inputs(c["seed"], V=c.get("V", 3), pad=c["pad"])
     if k == "rays":

@@ -111,6 +111,8 @@ def run(case, dtype=torch.float32, explicit=True):
             spec = spec_of(inp["P"], inp["Fd"], inp["sceneflow"], inp["static"], inp["use_mvs"],
                            inp["net_type"])
             out["y"] = zo.mlp_forward(state_t(inp["state"], dtype), T(inp["x"], dtype)[0], spec)
+        elif k == "loss_side":
+            pass                                    # needs autograd: below
         elif k == "homo_warp":
             feats, imgs = T(inp["feats"], dtype)[0], T(inp["imgs"], dtype)[0]
             H, W = feats.shape[-2:]
@@ -138,7 +140,22 @@ def run(case, dtype=torch.float32, explicit=True):
                            rays_mask_bwd_gt=T(inp["mask_bwd"], dtype)[:, -1, yi, xi])
         elif k == "render":
             out = oracle_render(c, inp, dtype, explicit)
+    if k == "loss_side":
+        out = loss_side(inp, dtype)
     return {kk: (v.double().numpy() if v is not None else None) for kk, v in out.items()}
+
+
+def loss_side(inp, dtype=torch.float32):
+    """Oracle distortion loss / ray projection with autograd gradients (fixture key names)."""
+    w = T(inp["weights"], dtype)[0].requires_grad_(True)
+    loss = zo.distortion_loss(w, T(inp["t_vals"], dtype))
+    loss.backward()
+    out = dict(distortion=loss.detach().reshape(1), distortion_dw=w.grad.clone())
+    w2, pts = T(inp["weights"], dtype)[0].requires_grad_(True), T(inp["pts"], dtype)[0].requires_grad_(True)
+    uv = zo.projection_from_ndc(T(inp["w2c"], dtype)[0], inp["H"], inp["W"], inp["f"], w2, pts)
+    (uv * T(inp["gw"], dtype)[0]).sum().backward()
+    out.update(uv=uv.detach(), uv_dw=w2.grad, uv_dpts=pts.grad)
+    return out
 
 
 def oracle_render_grads(case, dtype=torch.float32):

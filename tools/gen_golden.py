@@ -51,12 +51,13 @@ def import_reference():
     _placeholders()
     sys.path.insert(0, REF)
     mods = {}
-    for n in ("utils", "renderer", "networks"):
+    for n in ("utils", "renderer", "networks", "losses"):
         sys.modules.pop(n, None)
     import renderer as r
     import utils as u
     import networks as nw
-    mods.update(renderer=r, utils=u, networks=nw)
+    import losses as ls
+    mods.update(renderer=r, utils=u, networks=nw, losses=ls)
     sys.path.remove(REF)
     return SimpleNamespace(**mods)
 
@@ -110,6 +111,8 @@ def run_case(ref, name):
             net = ref_net(ref, inp["state"], inp["P"], inp["Fd"], inp["sceneflow"], inp["static"],
                           inp["use_mvs"], inp["net_type"])
             out["y"] = net(T(inp["x"])).numpy()[0]
+        elif k == "loss_side":
+            pass
         elif k == "homo_warp":
             out = run_homo_warp(ref.utils, inp)
         elif k == "rays":
@@ -118,6 +121,22 @@ def run_case(ref, name):
             out = run_render(ref, c, inp)
     if k == "render_grad":
         out = run_render_grad(ref, c, inp)
+    if k == "loss_side":
+        out = run_loss_side(ref, inp)
+    return out
+
+
+def run_loss_side(ref, inp):
+    """distortion_loss (losses.py:53-87) and projection_from_ndc (utils.py:527-539) with the
+    reference's own autograd for the gradients."""
+    w = T(inp["weights"]).requires_grad_(True)
+    loss = ref.losses.distortion_loss(w, T(inp["t_vals"]))
+    loss.backward()
+    out = dict(distortion=np.array([float(loss)]), distortion_dw=w.grad[0].numpy().copy())
+    w2, pts = T(inp["weights"]).requires_grad_(True), T(inp["pts"]).requires_grad_(True)
+    uv = ref.utils.projection_from_ndc(T(inp["w2c"]), inp["H"], inp["W"], inp["f"], w2, pts)
+    (uv * T(inp["gw"])).sum().backward()
+    out.update(uv=uv[0].detach().numpy(), uv_dw=w2.grad[0].numpy(), uv_dpts=pts.grad[0].numpy())
     return out
 
 

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libzest_hip.so")
-SOURCES = ["capi.hip", "composite.hip", "composite_bwd.hip", "encode.hip", "rays.hip", "volume_cost.hip", "mlp_plan.hip", "mlp.hip", "mlp_bf16.hip", "mlp_train.hip",
+SOURCES = ["capi.hip", "composite.hip", "composite_bwd.hip", "encode.hip", "rays.hip", "volume_cost.hip", "losses.hip", "mlp_plan.hip", "mlp.hip", "mlp_bf16.hip", "mlp_train.hip",
            "fused.hip", "fused_s0.hip", "fused_s2.hip", "fused_s4.hip", "fused_s0d0.hip",
            "fused_s4d2.hip", "fused_s2d2.hip", "fused_s2d0.hip", "fused_s4d0.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -70,6 +70,19 @@ def build_color_volume(point_samples, poses, imgs, img_feat=None, downscale=1.0,
     return out.view(*out.shape[:-1], V, 4)[..., :3].reshape(*out.shape[:-1], 3 * V)
 
 
+# ---------------------------------------------------------------------------- loss-side
+def projection_from_ndc(w2c, H, W, f, weights_ref, raw_pts):
+    """Expected 3-D point of every ray (sum_s w_s p_s over NDC points) -> Euclidean -> camera of
+    `w2c` -> pixel position [N,R,2] (reference utils.py:507-539).  One HIP
+    launch forward, one backward (gradients for the weights and the points)."""
+    import zest_autograd
+    if weights_ref.shape[0] != 1 or w2c.reshape(-1, 4, 4).shape[0] != 1:
+        raise RuntimeError("projection_from_ndc: batch must be 1 (the reference's broadcasting assumes it)")
+    out = zest_autograd.ProjectRaysFn.apply(weights_ref[0], raw_pts[0], w2c.reshape(4, 4).contiguous(),
+                                            int(H), int(W), float(f))
+    return out[None]
+
+
 # ---------------------------------------------------------------------------- plane sweep
 def homo_warp(src_feat, proj_mat, depth_values, src_grid=None, pad=0):
     """Warp a source feature map onto the fronto-parallel planes of the reference view

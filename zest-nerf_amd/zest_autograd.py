@@ -133,3 +133,38 @@ def mlp_apply(net, x):
         slots.append(slot)
         params += [named[name + ".weight"], named[name + ".bias"]]
     return MlpFn.apply(x, desc, tuple(slots), *params)
+
+
+class DistortionFn(Function):
+    """distortion_loss: per-ray O(S^2) pair sum and its weight gradient from one HIP launch."""
+
+    @staticmethod
+    def forward(ctx, weights, t_vals):
+        need = weights.requires_grad
+        loss_ray, grad = zest_hip.distortion(weights, t_vals, want_grad=need)
+        if need:
+            ctx.save_for_backward(grad)
+        return loss_ray.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None
+
+
+class ProjectRaysFn(Function):
+    """projection_from_ndc: expected point -> Euclidean -> camera -> pixels, fused per ray."""
+
+    @staticmethod
+    def forward(ctx, weights, pts, w2c, H, W, focal):
+        ctx.cfg = (H, W, focal)
+        ctx.save_for_backward(weights, pts, w2c)
+        return zest_hip.project_rays(weights, pts, w2c, H, W, focal)
+
+    @staticmethod
+    def backward(ctx, g):
+        weights, pts, w2c = ctx.saved_tensors
+        H, W, focal = ctx.cfg
+        dw, dp = zest_hip.project_rays_bwd(weights, pts, w2c, H, W, focal, g.contiguous(),
+                                           ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return dw, dp, None, None, None, None

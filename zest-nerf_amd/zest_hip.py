@@ -54,6 +54,9 @@ _SIGS = {
     "zest_volume_to_cl": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "zest_images_to_cl": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "zest_nchw_to_nhwc": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "zest_distortion_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "zest_project_rays_fwd": (_i, [_vp, _vp, _vp, _i, _i, _f, _i, _i, _vp, _vp]),
+    "zest_project_rays_bwd": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _i, _i, _vp, _vp, _vp]),
     "zest_volume_cost_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "zest_homo_warp_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "zest_volume_lookup_fwd": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
@@ -191,6 +194,39 @@ def volume_to_cl(vol):
     out = torch.empty(D, H, W, 8, device=vol.device, dtype=torch.float32)
     _check(lib().zest_volume_to_cl(_ptr(vol), D, H, W, _ptr(out), _stream(vol)), "zest_volume_to_cl")
     return out
+
+
+def distortion(weights, t_vals, want_grad=True):
+    """weights [R,S], t_vals [1,S] or [R,S] -> (loss_ray [R], d loss_ray / d weights [R,S] or None)."""
+    weights, t_vals = _dev(weights, "ray_weights"), _dev(t_vals, "t_vals")
+    R, S = weights.shape
+    loss = torch.empty(R, device=weights.device, dtype=torch.float32)
+    grad = torch.empty(R, S, device=weights.device, dtype=torch.float32) if want_grad else None
+    _check(lib().zest_distortion_fwd(_ptr(weights), _ptr(t_vals), t_vals.shape[0], R, S, _ptr(loss), _ptr(grad),
+                                     _stream(weights)), "zest_distortion_fwd")
+    return loss, grad
+
+
+def project_rays(weights, pts, w2c, H, W, focal):
+    """weights [R,S], pts [R,S,3], w2c [4,4] (or [3,4]) -> [R,2]."""
+    weights, pts, w2c = _dev(weights, "weights_ref"), _dev(pts, "raw_pts"), _dev(w2c, "w2c")
+    R, S = weights.shape
+    out = torch.empty(R, 2, device=weights.device, dtype=torch.float32)
+    _check(lib().zest_project_rays_fwd(_ptr(weights), _ptr(pts), _ptr(w2c), int(H), int(W), float(focal), R, S,
+                                       _ptr(out), _stream(weights)), "zest_project_rays_fwd")
+    return out
+
+
+def project_rays_bwd(weights, pts, w2c, H, W, focal, grad_out, want_w=True, want_pts=True):
+    weights, pts, w2c, grad_out = (_dev(weights, "weights_ref"), _dev(pts, "raw_pts"), _dev(w2c, "w2c"),
+                                   _dev(grad_out, "grad"))
+    R, S = weights.shape
+    dw = torch.empty(R, S, device=weights.device, dtype=torch.float32) if want_w else None
+    dp = torch.empty(R, S, 3, device=weights.device, dtype=torch.float32) if want_pts else None
+    _check(lib().zest_project_rays_bwd(_ptr(weights), _ptr(pts), _ptr(w2c), int(H), int(W), float(focal),
+                                       _ptr(grad_out), R, S, _ptr(dw), _ptr(dp), _stream(weights)),
+           "zest_project_rays_bwd")
+    return dw, dp
 
 
 def nchw_to_nhwc(x):

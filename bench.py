@@ -252,7 +252,7 @@ def main():
                                       % (IMAGE_PIXELS, per_image))},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(a.workload),
-                         "kernel": "fused_blocks_kernel (+ fused_combine_kernel, ~3% of the bracket)",
+                         "kernel": "fused_blocks_kernel (rays finished in-kernel when 8 blocks hold whole rays; else + fused_combine_kernel)",
                          "kernel_ms": k_ms, "flop_per_sample": fps,
                          "note": "achieved = algorithmic MLP FLOPs of one launch / HIP-event time of the "
                                  "launch pair on its stream; traffic = HBM bytes per launch from the "

@@ -6,8 +6,11 @@
 // source views are split over the four groups), the bf16 engine (mlp_engine.cuh) runs the
 // whole network on them with the weights streamed through an LDS ring shared by the workgroup,
 // and the raw colour/density land on lanes 0-15 of each column block; one v_permlane16_swap
-// per value lines the 32 samples up on lanes 0-31, where a shuffle scan composites the block.  Per block 80 B leave the chip; a second tiny kernel chains the blocks of each ray
-// into the per-ray maps (64 B per ray).
+// per value lines the 32 samples up on lanes 0-31, where a shuffle scan composites the block.
+// Each block is composited with entry transmittance 1 and leaves an 80-byte record; the records
+// of a ray are chained into the per-ray maps (64 B per ray) either right here - when the 8
+// blocks of a pass hold whole rays (S <= 256 in steps that divide 8 blocks), the records never
+// leave LDS - or by a second tiny kernel (fused_combine_kernel) from an HBM workspace.
 //
 // Replaces rendering(..., val=True) of the reference (renderer.py:579-626 with the early
 // return at :444-445): prepare_pts / prepare_dynamic_pts, gen_pts_feats, run_network,
@@ -41,7 +44,36 @@ struct FusedArgs {
     float *partials;                      // [R*bpr, kPartialFloats] workspace
     float *out;                           // [R,16]
     unsigned long long *stamps;           // diagnostic builds (ZEST_STAMPS): 8 u64 per wave, else null
+    int combine_in_kernel;                // bpr divides the blocks of a pass: rays are finished in the pass
 };
+
+// Chains the per-block records of one ray (exit transmittance + weighted sums, entry
+// transmittance 1 each) into the per-ray maps: column layout of include/zest_render.h.
+template <class Rec>
+__device__ __forceinline__ void combine_ray(Rec rec, int bpr, bool dyn, int white_bkgd, float *__restrict__ out_row) {
+    float Ts = 1.f, Tb = 1.f, Tf = 1.f;
+    float s[5] = {0, 0, 0, 0, 0}, bl[5] = {0, 0, 0, 0, 0}, fg[4] = {0, 0, 0, 0};
+    for (int b = 0; b < bpr; b++) {
+        const float *p = rec(b);
+#pragma unroll
+        for (int i = 0; i < 5; i++) s[i] += Ts * p[1 + i];
+        Ts *= p[0];
+        if (dyn) {
+#pragma unroll
+            for (int i = 0; i < 5; i++) bl[i] += Tb * p[7 + i];
+            Tb *= p[6];
+#pragma unroll
+            for (int i = 0; i < 4; i++) fg[i] += Tf * p[13 + i];
+            Tf *= p[12];
+        }
+    }
+    float4 *o = reinterpret_cast<float4 *>(out_row);
+    const float bg = white_bkgd ? 1.0f - s[4] : 0.0f;
+    o[0] = make_float4(s[0] + bg, s[1] + bg, s[2] + bg, s[3]);
+    o[1] = make_float4(s[4], bl[0], bl[1], bl[2]);
+    o[2] = make_float4(bl[3], fg[0], fg[1], fg[2]);
+    o[3] = make_float4(fg[3], bl[4], 0.f, 0.f);
+}
 
 __device__ __forceinline__ bf16x8 pack_tile(const float (&v)[8]) {
     uint4 a = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]),
@@ -204,13 +236,15 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
     using Ring = RingTiles<kFusedWaves, UNITS_S, UNITS_D>;
     // LDS: weight ring | cameras of both nets | per-lane (z, dist) of the pass's samples
     __shared__ __attribute__((aligned(16))) char lds[kRingUnits * 1024 + 2 * kMaxViews * kCamStride * 4 +
-                                                     kFusedWaves * NB * 32 * 8 + 2 * kSlots * 4];
+                                                     kFusedWaves * NB * 32 * 8 + 2 * kSlots * 4 +
+                                                     kFusedWaves * NB * kPartialFloats * 4];
     float *cams_s = reinterpret_cast<float *>(lds + kRingUnits * 1024), *cams_d = cams_s + kMaxViews * kCamStride;
     float2 *zd_lds = reinterpret_cast<float2 *>(cams_d + kMaxViews * kCamStride);
     stage_cams(a.st, cams_s);
     if (DYN) stage_cams(a.dy, cams_d);
-#ifdef ZEST_RING_FLAGS
     int *ring_flags = reinterpret_cast<int *>(zd_lds + kFusedWaves * NB * 32);
+    float *rec_lds = reinterpret_cast<float *>(ring_flags + 2 * kSlots);      // [waves * NB][kPartialFloats]
+#ifdef ZEST_RING_FLAGS
     Ring::init_flags(ring_flags);
 #endif
     __syncthreads();
@@ -374,10 +408,27 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
                 rec[16] = lower_half_sum(wf * b.zz);
             }
             if (lane == 0 && gidx >= 0) {
-                float4 *o = reinterpret_cast<float4 *>(a.partials + (size_t)gidx * kPartialFloats);
+                // records go to HBM for combine_kernel, or stay in LDS when the pass holds whole rays
+                float4 *o = a.combine_in_kernel
+                                ? reinterpret_cast<float4 *>(rec_lds + (wave * NB + nb) * kPartialFloats)
+                                : reinterpret_cast<float4 *>(a.partials + (size_t)gidx * kPartialFloats);
 #pragma unroll
                 for (int i = 0; i < (DYN ? 5 : 2); i++)
                     o[i] = make_float4(rec[4 * i], rec[4 * i + 1], rec[4 * i + 2], rec[4 * i + 3]);
+            }
+        }
+        if (a.combine_in_kernel) {
+            // The blocks of a ray sit in consecutive waves of this pass: after one rendezvous the
+            // wave holding a ray's first block chains the records (80 B each, in LDS) and writes
+            // the ray's maps - no record traffic, no second launch.  The next pass cannot reach
+            // this point before every wave has passed the ring's chunk barriers, i.e. has left it.
+            __syncthreads();
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) {
+                const int slot = wave * NB + nb, g_ = pass * (kFusedWaves * NB) + slot;
+                if (lane == 0 && g_ < n_blocks && g_ % a.bpr == 0)
+                    combine_ray([&](int b) { return rec_lds + (slot + b) * kPartialFloats; }, a.bpr, DYN,
+                                a.white_bkgd, a.out + (size_t)(g_ / a.bpr) * 16);
             }
         }
         ZEST_STAMP(st_comp);

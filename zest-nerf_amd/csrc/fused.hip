@@ -12,28 +12,8 @@ __global__ void fused_combine_kernel(const float *__restrict__ partials, int R, 
                                      int white_bkgd, float *__restrict__ out) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
-    float Ts = 1.f, Tb = 1.f, Tf = 1.f;
-    float s[5] = {0, 0, 0, 0, 0}, bl[5] = {0, 0, 0, 0, 0}, fg[4] = {0, 0, 0, 0};
-    for (int b = 0; b < bpr; b++) {
-        const float *p = partials + ((size_t)r * bpr + b) * kPartialFloats;
-#pragma unroll
-        for (int i = 0; i < 5; i++) s[i] += Ts * p[1 + i];
-        Ts *= p[0];
-        if (dyn) {
-#pragma unroll
-            for (int i = 0; i < 5; i++) bl[i] += Tb * p[7 + i];
-            Tb *= p[6];
-#pragma unroll
-            for (int i = 0; i < 4; i++) fg[i] += Tf * p[13 + i];
-            Tf *= p[12];
-        }
-    }
-    float4 *o = reinterpret_cast<float4 *>(out + (size_t)r * 16);
-    const float bg = white_bkgd ? 1.0f - s[4] : 0.0f;
-    o[0] = make_float4(s[0] + bg, s[1] + bg, s[2] + bg, s[3]);
-    o[1] = make_float4(s[4], bl[0], bl[1], bl[2]);
-    o[2] = make_float4(bl[3], fg[0], fg[1], fg[2]);
-    o[3] = make_float4(fg[3], bl[4], 0.f, 0.f);
+    combine_ray([&](int b) { return partials + ((size_t)r * bpr + b) * kPartialFloats; }, bpr, dyn != 0,
+                white_bkgd, out + (size_t)r * 16);
 }
 
 }  // namespace zest
@@ -129,6 +109,9 @@ extern "C" int zest_render_fused_fwd(const float *ndc, const float *pts, const f
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         cus = 256;
     const int n_pass = zest_div_up((long long)R * a.bpr, zest::kFusedWaves * zest::kFusedNB);
+    // whole rays per pass (bpr divides the pass's blocks: S <= 32, 64, 128 or 256 with 8 waves):
+    // the kernel finishes the rays itself and the combine launch is skipped
+    a.combine_in_kernel = (zest::kFusedWaves * zest::kFusedNB) % a.bpr == 0 ? 1 : 0;
     int blocks = cus;                                               // set per variant below
     hipStream_t st = (hipStream_t)stream;
     const int key = (dyn ? 100 : 0) + nts * 10 + ntd;
@@ -157,7 +140,7 @@ extern "C" int zest_render_fused_fwd(const float *ndc, const float *pts, const f
             return (int)hipErrorInvalidValue;
     }
 #undef ZEST_CASE
-    if (rc != 0) return rc;
+    if (rc != 0 || a.combine_in_kernel) return rc;
     hipLaunchKernelGGL(zest::fused_combine_kernel, dim3(zest_div_up(R, 128)), dim3(128), 0, st,
                        a.partials, R, a.bpr, dyn ? 1 : 0, white_bkgd, out);
     ZEST_RETURN_LAUNCH("zest_render_fused_fwd(combine)");

@@ -114,58 +114,67 @@ __global__ __launch_bounds__(64) void volume_cost_kernel(
             toff[(i - 1) * 64 + lane] = make_int4(t.off[0], t.off[1], t.off[2], t.off[3]);
             tw[(i - 1) * 64 + lane] = make_float4(t.w[0], t.w[1], t.w[2], t.w[3]);
         }
-        vox[lane] = make_float4(__int_as_float(live ? (inside ? yr * W + xr : -1) : -2), 1.0f / count,
+        vox[lane] = make_float4(__int_as_float(live && inside ? yr * W + xr : -1), 1.0f / count,
                                 __int_as_float(in_frame), 0.0f);
     }
     __syncthreads();
-    // ---- phase 2: lane = (voxel of the octet, channel quad)
+    // ---- phase 2: lane = (voxel of the octet, channel quad).  Branch-free, so the eight octets
+    // form one basic block and the compiler keeps the loads of several of them in flight
+    // (voxels past the end of the volume compute on clamped addresses and are dropped at the
+    // final store).
 #pragma unroll
     for (int it = 0; it < 8; it++) {
         const int v = it * 8 + vsub;
         const float4 g = vox[v];
         const int ref_off = __float_as_int(g.x);
-        if (ref_off == -2) continue;                           // past the end of the volume
+        const bool has_ref = ref_off >= 0;
         // reference view: its own feature map, zero in the padding ring
-        float4 sum = ref_off >= 0 ? feats[(size_t)ref_off * (kC / 4) + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 rf = feats[(size_t)(has_ref ? ref_off : 0) * (kC / 4) + q];
+        float4 sum = has_ref ? rf : make_float4(0.f, 0.f, 0.f, 0.f);
         float4 sq = make_float4(sum.x * sum.x, sum.y * sum.y, sum.z * sum.z, sum.w * sum.w);
-        if (q == 0) {
-            // the reference leaves channels 0-2 of the padding ring uninitialised (torch.empty); 0 here
-            const float4 c0 = ref_off >= 0 ? imgs[ref_off] : make_float4(0.f, 0.f, 0.f, 0.f);
-            tile[0 * kRowStride + v] = c0.x, tile[1 * kRowStride + v] = c0.y, tile[2 * kRowStride + v] = c0.z;
-            tile[(3 * V + kC) * kRowStride + v] = 1.0f;
-        }
 #pragma unroll
         for (int i = 1; i < V; i++) {
             const int4 o4 = toff[(i - 1) * 64 + v];
             const float4 w4 = tw[(i - 1) * 64 + v];
-            Tap4 t;
-            t.off[0] = o4.x, t.off[1] = o4.y, t.off[2] = o4.z, t.off[3] = o4.w;
-            t.w[0] = w4.x, t.w[1] = w4.y, t.w[2] = w4.z, t.w[3] = w4.w;
             const float4 *f = feats + (size_t)i * H * W * (kC / 4);
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
 #ifdef ZEST_EXPERIMENT_NO_GATHER       // timing experiment only
-                const float4 tv = make_float4(t.w[c], 1.f, 2.f, 3.f);
+            const float4 t0 = w4, t1 = w4, t2 = w4, t3 = w4;
 #else
-                const float4 tv = f[(size_t)t.off[c] * (kC / 4) + q];
+            const float4 t0 = f[(size_t)o4.x * (kC / 4) + q], t1 = f[(size_t)o4.y * (kC / 4) + q],
+                         t2 = f[(size_t)o4.z * (kC / 4) + q], t3 = f[(size_t)o4.w * (kC / 4) + q];
 #endif
-                a.x = fmaf(t.w[c], tv.x, a.x), a.y = fmaf(t.w[c], tv.y, a.y);
-                a.z = fmaf(t.w[c], tv.z, a.z), a.w = fmaf(t.w[c], tv.w, a.w);
-            }
+            float4 a;
+            a.x = fmaf(w4.w, t3.x, fmaf(w4.z, t2.x, fmaf(w4.y, t1.x, w4.x * t0.x)));
+            a.y = fmaf(w4.w, t3.y, fmaf(w4.z, t2.y, fmaf(w4.y, t1.y, w4.x * t0.y)));
+            a.z = fmaf(w4.w, t3.z, fmaf(w4.z, t2.z, fmaf(w4.y, t1.z, w4.x * t0.z)));
+            a.w = fmaf(w4.w, t3.w, fmaf(w4.z, t2.w, fmaf(w4.y, t1.w, w4.x * t0.w)));
             sum.x += a.x, sum.y += a.y, sum.z += a.z, sum.w += a.w;
             sq.x = fmaf(a.x, a.x, sq.x), sq.y = fmaf(a.y, a.y, sq.y), sq.z = fmaf(a.z, a.z, sq.z), sq.w = fmaf(a.w, a.w, sq.w);
-            if (q == (i & 7)) {                                // the image taps: one lane of the octet per view
-                const float4 *im = imgs + (size_t)i * H * W;
-                float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        // images: the octet's 8 lanes take one bilinear tap each - lanes 4j .. 4j+3 the four taps of
+        // one view - and add them up with two quad shuffles; rounds of two views
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const float4 tv = im[t.off[c]];
-                    b.x = fmaf(t.w[c], tv.x, b.x), b.y = fmaf(t.w[c], tv.y, b.y), b.z = fmaf(t.w[c], tv.z, b.z);
-                }
-                tile[(3 * i) * kRowStride + v] = b.x, tile[(3 * i + 1) * kRowStride + v] = b.y;
-                tile[(3 * i + 2) * kRowStride + v] = b.z;
-                tile[(3 * V + kC + i) * kRowStride + v] = ((__float_as_int(g.z) >> i) & 1) ? 1.0f : 0.0f;
+        for (int i0 = 0; i0 < V; i0 += 2) {
+            const int iv = i0 + (q >> 2), c = q & 3;            // view of this lane, tap of this lane
+            const bool ok = iv < V;
+            const int ivc = ok ? iv : 0;
+            // view 0 is the reference image itself (one tap of weight 1, zero in the padding ring);
+            // lanes beyond the last view read view 1's entry with weight 0
+            const int vi = (ok && ivc > 0) ? ivc - 1 : 0;      // index into the per-source-view geometry
+            const int4 o4 = toff[vi * 64 + v];
+            const float4 w4 = tw[vi * 64 + v];
+            const int off = ivc == 0 ? (has_ref ? ref_off : 0) : (c == 0 ? o4.x : c == 1 ? o4.y : c == 2 ? o4.z : o4.w);
+            const float wsel = c == 0 ? w4.x : c == 1 ? w4.y : c == 2 ? w4.z : w4.w;
+            const float wgt = !ok ? 0.0f : (ivc == 0 ? ((has_ref && c == 0) ? 1.0f : 0.0f) : wsel);
+            const float4 tv = imgs[(size_t)ivc * H * W + off];
+            float bx = wgt * tv.x, by = wgt * tv.y, bz = wgt * tv.z;
+            bx += __shfl_xor(bx, 1, 64), by += __shfl_xor(by, 1, 64), bz += __shfl_xor(bz, 1, 64);
+            bx += __shfl_xor(bx, 2, 64), by += __shfl_xor(by, 2, 64), bz += __shfl_xor(bz, 2, 64);
+            if (c == 0 && ok) {
+                // the reference leaves channels 0-2 of the padding ring uninitialised (torch.empty); 0 here
+                tile[(3 * iv) * kRowStride + v] = bx, tile[(3 * iv + 1) * kRowStride + v] = by;
+                tile[(3 * iv + 2) * kRowStride + v] = bz;
+                tile[(3 * V + kC + iv) * kRowStride + v] = ((__float_as_int(g.z) >> iv) & 1) ? 1.0f : 0.0f;
             }
         }
         const float inv = g.y;
@@ -183,9 +192,11 @@ __global__ __launch_bounds__(64) void volume_cost_kernel(
 #ifdef ZEST_EXPERIMENT_NO_WRITE        // timing experiment only
         if (tile[r * kRowStride + lane] == 123456.0f)
 #endif
-        img_feat[(size_t)r * nvox + idx] = tile[r * kRowStride + lane];
+        // streaming stores: 475 MB of output must not evict the few MB of feature maps from L2
+        __builtin_nontemporal_store(tile[r * kRowStride + lane], &img_feat[(size_t)r * nvox + idx]);
     }
-    for (int i = 0; i < V; i++) in_masks[(size_t)i * nvox + idx] = tile[(3 * V + kC + i) * kRowStride + lane];
+    for (int i = 0; i < V; i++)
+        __builtin_nontemporal_store(tile[(3 * V + kC + i) * kRowStride + lane], &in_masks[(size_t)i * nvox + idx]);
 }
 
 // src [C,H,W]; grid_in (optional) [D,Hp,Wp,2] normalised positions to reuse; outputs

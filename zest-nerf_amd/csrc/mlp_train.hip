@@ -147,21 +147,34 @@ __global__ void react_kernel(const float *__restrict__ pre, const float *__restr
     const float p = pre[i];
     act[i] = fmaxf(m ? (v2 ? p + m[i] : p * m[i]) : p, 0.f);
 }
-// d (in: dL/dact, out: dL/dpre) and dm += dL/dm, through relu(mod(pre, m))
-__global__ void act_bwd_kernel(float *__restrict__ d, const float *__restrict__ pre,
-                               const float *__restrict__ m, float *__restrict__ dm, long long n_elem, int v2) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_elem) return;
-    const float p = pre[i], g = d[i];
-    if (!m) {
-        d[i] = p > 0.f ? g : 0.f;
-        return;
+// d (in: dL/dact, out: dL/dpre) and dm += dL/dm, through relu(mod(pre, m)), with the bias gradient
+// folded in: db[n] += sum over the block's rows of dL/dpre.
+// One thread per column (N = 128 or 256 columns = blockDim.x), kBwdRows rows per block: the
+// separate column-sum pass over dL/dpre (11 % of a training step) disappears.
+constexpr int kBwdRows = 64;
+__global__ void act_bwd_colsum_kernel(float *__restrict__ d, const float *__restrict__ pre,
+                                      const float *__restrict__ m, float *__restrict__ dm, int M, int N, int v2,
+                                      float *__restrict__ db) {
+    const int n = threadIdx.x;
+    const int m0 = blockIdx.x * kBwdRows, m1 = min(m0 + kBwdRows, M);
+    float acc = 0.f;
+    for (int r = m0; r < m1; r++) {
+        const size_t i = (size_t)r * N + n;
+        const float p = pre[i], g = d[i];
+        float out;
+        if (!m) {
+            out = p > 0.f ? g : 0.f;
+        } else {
+            const float mv = m[i];
+            const bool on = (v2 ? p + mv : p * mv) > 0.f;
+            const float go = on ? g : 0.f;
+            out = v2 ? go : go * mv;
+            dm[i] += v2 ? go : go * p;
+        }
+        d[i] = out;
+        acc += out;
     }
-    const float mv = m[i];
-    const bool on = (v2 ? p + mv : p * mv) > 0.f;
-    const float go = on ? g : 0.f;
-    d[i] = v2 ? go : go * mv;
-    dm[i] += v2 ? go : go * p;
+    atomicAdd(db + n, acc);
 }
 __global__ void fill_kernel(float *__restrict__ p, long long n, float v) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -335,11 +348,12 @@ extern "C" int zest_mlp_train_bwd(const zest_mlp_desc *desc, const float *const 
     RB(gemm_dw(cx, M, 3, HW, dhp, 16, act, HW, g.w[ZEST_P_RGB], HW));
     RB(col_sums(cx, M, 3, dhp, 16, g.b[ZEST_P_RGB]));
     RB(gemm_dx(h, M, 3, HW, dhp, 16, p.w[ZEST_P_RGB], HW, dhv, HW, 0.f));
-    EW(act_bwd_kernel, MH, dhv, hvpre, (const float *)nullptr, (float *)nullptr, MH, 0);
+    hipLaunchKernelGGL(zero_kernel, dim3(1), dim3(256), 0, st, g.b[ZEST_P_VIEWS], HW);
+    hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3((M + kBwdRows - 1) / kBwdRows), dim3(HW), 0, st, dhv, hvpre,
+                       (const float *)nullptr, (float *)nullptr, M, HW, 0, g.b[ZEST_P_VIEWS]);
     // views_linears.0 on [feature | views]
     RB(gemm_dw(cx, M, HW, W, dhv, HW, featl, W, g.w[ZEST_P_VIEWS], W + s.V));
     RB(gemm_dw(cx, M, HW, s.V, dhv, HW, xv, s.C_in, g.w[ZEST_P_VIEWS] + W, W + s.V));
-    RB(col_sums(cx, M, HW, dhv, HW, g.b[ZEST_P_VIEWS]));
     RB(gemm_dx(h, M, HW, W, dhv, HW, p.w[ZEST_P_VIEWS], W + s.V, dfeat, W, 0.f));
     // trunk output h7 = relu(mod(pre7, m)): feature_linear, alpha and the extra heads read it
     EW(react_kernel, MW, pre[7], mbuf, act, MW, s.v2);
@@ -363,8 +377,10 @@ extern "C" int zest_mlp_train_bwd(const zest_mlp_desc *desc, const float *const 
     // trunk, last layer first.  da = dL/d(act_l) on entry to layer l.
     float *dcur = da, *dnxt = db_;
     for (int l = 7; l >= 0; l--) {
-        EW(act_bwd_kernel, MW, dcur, pre[l], mbuf, dm, MW, s.v2);           // dcur = dL/dpre_l
-        RB(col_sums(cx, M, W, dcur, W, g.b[l]));
+        // dcur = dL/dpre_l, and its column sums = the bias gradient
+        hipLaunchKernelGGL(zero_kernel, dim3(1), dim3(256), 0, st, g.b[l], W);
+        hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3((M + kBwdRows - 1) / kBwdRows), dim3(W), 0, st, dcur, pre[l],
+                           mbuf, dm, M, W, s.v2, g.b[l]);
         if (l == 0) {
             RB(gemm_dw(cx, M, W, s.P, dcur, W, xp, s.C_in, g.w[0], s.P));
             if (g_x) RB(gemm_dx(h, M, W, s.P, dcur, W, p.w[0], s.P, gxp, s.C_in, 1.f));

@@ -20,7 +20,8 @@ import torch.nn as nn
 import zest_hip
 
 __all__ = ["Embedding", "Renderer", "Renderer_linear", "MVSNeRF", "resolve_precision",
-           "ActivatedBatchNorm", "ConvBnReLU", "ConvBnReLU3D", "FeatureNet", "CostRegNet", "MVSNet"]
+           "ActivatedBatchNorm", "ConvBnReLU", "ConvBnReLU3D", "FeatureNet", "CostRegNet", "MVSNet",
+           "MVSNeRF_G", "DyMVSNeRF_G"]
 
 
 def resolve_precision(args=None):
@@ -355,3 +356,170 @@ class MVSNet(nn.Module):
         volume_feat, _ = self.cost_reg_2(cost_vol)
         volume_feat = volume_feat.reshape(1, -1, *volume_feat.shape[2:])
         return volume_feat, feats, depth_values
+
+
+# ------------------------------------------------------------------------------------------
+# Generators: the callers of the path (reference networks.py:355-720).  Host orchestration only:
+# encoding volume(s) -> ray sampling -> rendering, with the reference's constructor arguments,
+# batch-dict keys and result keys.  The whole-image loop of forward_val additionally shards its
+# ray chunks over the ranks of an initialised torch.distributed group (each rank
+# renders its own chunks, ONE all-gather per image) and takes the fused single-launch renderer.
+_IMAGENET = ((-0.485 / 0.229, -0.456 / 0.224, -0.406 / 0.225), (1 / 0.229, 1 / 0.224, 1 / 0.225))
+
+
+class _Generator(nn.Module):
+    def unpreprocess(self, data, shape=(1, 1, 3, 1, 1)):
+        """Undo the ImageNet normalisation of the loader (N V C H W)."""
+        mean = torch.tensor(_IMAGENET[0], device=data.device).view(*shape)
+        std = torch.tensor(_IMAGENET[1], device=data.device).view(*shape)
+        return (data - mean) / std
+
+    def _volume(self, net, imgs, proj_mats, near_far, bn_batch_stats=False):
+        """Encoding volume of `net` (None -> no volume).  The HIP plane sweep is forward only, so the
+        builder runs without autograd; a builder whose parameters want gradients is refused."""
+        if net is None:
+            return None
+        if torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters()):
+            raise NotImplementedError("the MVS volume builder is forward only here: freeze it "
+                                      "(requires_grad_(False)) or run under torch.no_grad()")
+        if bn_batch_stats:
+            net.train()         # the reference validates with batch statistics (networks.py:629, 644)
+        with torch.no_grad():
+            return net(imgs, proj_mats, near_far, pad=self.args.pad)[0]
+
+
+class MVSNeRF_G(_Generator):
+    """Static generator (reference networks.py:355-446)."""
+
+    def __init__(self, args, nerf, encoding, embedding_pts, embedding_dir):
+        super().__init__()
+        self.nerf, self.encoding_net = nerf, encoding
+        self.embedding_pts, self.embedding_dir = embedding_pts, embedding_dir
+        self.N_rays, self.N_samples, self.args = args.batch_size, args.N_samples, args
+
+    def forward(self, x, step=0, time_codes=None):
+        import utils
+        from renderer import rendering
+        imgs = x['images']
+        depths = x['depths_h'] if 'depths_h' in x else x['depths']
+        cams = {'w2cs': x['w2cs'], 'intrinsics': x['intrinsics']}
+        volume = self._volume(self.encoding_net, imgs[:, :-1], x['proj_mats'][:, :-1], x['near_fars'][0, 0])
+        pad = self.args.pad if self.encoding_net is not None else 0
+        imgs = self.unpreprocess(imgs)
+        rays_pts, rays_dir, target_s, rays_ndc, depth_candidates, rays_depth_gt, t_vals = utils.build_rays(
+            imgs, depths, x['w2cs'], x['c2ws'], x['intrinsics'], x['near_fars'], self.N_samples,
+            N_rays=self.N_rays, pad=pad, patch_size=self.args.patch_size, scale_anneal=self.args.scale_anneal,
+            step=step, variable_patches=(self.args.gan_type == 'graf'))
+        ret = rendering(self.args, rays_pts, rays_ndc, depth_candidates, rays_dir, volume_feature_static=volume,
+                        imgs=imgs[:, :-1], img_feat=None, im_cam_mat=cams, network_fn=self.nerf,
+                        embedding_pts=self.embedding_pts, embedding_dir=self.embedding_dir,
+                        time_codes=time_codes, white_bkgd=self.args.white_bkgd)
+        ret.update(target_s=target_s, depth_gt=rays_depth_gt, t_vals=t_vals)
+        return ret
+
+
+class DyMVSNeRF_G(_Generator):
+    """Static + dynamic (scene-flow) generator (reference networks.py:448-720)."""
+
+    VAL_KEYS = ('rgb_map_ref', 'depth_map_ref', 'rgb_map', 'depth_map', 'rgb_map_ref_dy', 'depth_map_ref_dy',
+                'weights_map_dd')
+
+    def __init__(self, args, decay_iteration, nerf_dynamic, nerf_static, encoding, encoding_dy, embedding_pts,
+                 embedding_xyzt, embedding_dir):
+        super().__init__()
+        self.nerf_dynamic, self.nerf_static = nerf_dynamic, nerf_static
+        self.encoding_net, self.encoding_net_dy = encoding, encoding_dy
+        self.embedding_pts, self.embedding_xyzt, self.embedding_dir = embedding_pts, embedding_xyzt, embedding_dir
+        self.N_rays, self.N_samples = args.batch_size, args.N_samples
+        self.chain_bwd, self.decay_iteration, self.args = False, decay_iteration, args
+
+    def _scene(self, x, bn_batch_stats=False):
+        """Volumes, unnormalised images and cameras of one batch dict."""
+        sc = dict(cams={'w2cs': x['w2cs'], 'intrinsics': x['intrinsics']}, nb_frames=None, nb_cams=None)
+        imgs, near_far = x['images'], x['near_fars'][0, 0]
+        sc['vol_s'] = self._volume(self.encoding_net, imgs[:, :-1], x['proj_mats'][:, :-1], near_far, bn_batch_stats)
+        sc['vol_d'] = None
+        if self.encoding_net_dy is not None:
+            sc['nb_cams'] = {'w2cs': x['nb_w2cs'], 'intrinsics': x['nb_intr']}
+            sc['vol_d'] = self._volume(self.encoding_net_dy, x['nb_imgs'], x['nb_proj_mats'], near_far, bn_batch_stats)
+            sc['nb_frames'] = self.unpreprocess(x['nb_imgs'])
+        sc['pad'] = self.args.pad if (self.encoding_net is not None or self.encoding_net_dy is not None) else 0
+        sc['imgs'] = self.unpreprocess(imgs)
+        frame_t, sc['num_frames'] = x['time'].item(), x['total_frames'].item()
+        sc['ref_frame_idx'] = frame_t / sc['num_frames'] * 2. - 1.0
+        return sc
+
+    def _render(self, sc, rays, time_codes, **kw):
+        from renderer import rendering
+        rays_pts, rays_dir, rays_ndc, depth_candidates = rays
+        return rendering(self.args, rays_pts, rays_ndc, depth_candidates, rays_dir,
+                         volume_feature_static=sc['vol_s'], volume_feature_dynamic=sc['vol_d'],
+                         imgs=sc['imgs'][:, :-1], neighbour_frames=sc['nb_frames'], im_cam_mat=sc['cams'],
+                         nb_cam_mat=sc['nb_cams'], network_fn=self.nerf_static, network_fn_dy=self.nerf_dynamic,
+                         embedding_pts=self.embedding_pts, embedding_xyzt=self.embedding_xyzt,
+                         embedding_dir=self.embedding_dir, time_codes=time_codes, white_bkgd=self.args.white_bkgd,
+                         scene_flow=True, chain_bwd=self.chain_bwd, ref_frame_idx=sc['ref_frame_idx'],
+                         num_frames=sc['num_frames'], **kw)
+
+    def forward(self, x, step=0, time_codes=None):
+        import utils
+        a = self.args
+        chain_5frames = bool(a.with_chain_loss and step > self.decay_iteration * 1000 * 2)
+        extra = a.num_extra_samples if (a.use_motion_mask and step < self.decay_iteration * 1000) else 0
+        sc = self._scene(x)
+        (rays_pts, rays_dir, target_s, rays_ndc, depth_candidates, rays_depth_gt, t_vals, flow_fwd, flow_bwd,
+         mask_fwd, mask_bwd) = utils.build_rays_dy(
+            sc['imgs'], x['depths'], x['w2cs'], x['c2ws'], x['intrinsics'], x['near_fars'], self.N_samples,
+            N_rays=self.N_rays, pad=sc['pad'], patch_size=a.patch_size, scale_anneal=a.scale_anneal,
+            num_extra_samples=extra, motion_coords=x['motion_coords'][-1], step=step,
+            variable_patches=(a.gan_type == 'graf'), scene_flow=True, flow_fwd=x['flow_fwds'],
+            flow_bwd=x['flow_bwds'], mask_fwd=x['mask_fwds'], mask_bwd=x['mask_bwds'])
+        self.chain_bwd = not self.chain_bwd          # alternate the direction of the scene-flow chain
+        ret = self._render(sc, (rays_pts, rays_dir, rays_ndc, depth_candidates), time_codes,
+                           chain_5frames=chain_5frames, raw_noise_std=a.raw_noise_std)
+        ret.update(target_s=target_s, depth_gt=rays_depth_gt, t_vals=t_vals, rays_flow_fwd_gt=flow_fwd,
+                   rays_flow_bwd_gt=flow_bwd, rays_mask_fwd_gt=mask_fwd, rays_mask_bwd_gt=mask_bwd,
+                   chain_bwd=self.chain_bwd, chain_5frames=chain_5frames)
+        return ret
+
+    def forward_val(self, x, time_codes=None):
+        """Whole-image evaluation in chunks of args.chunk rays -> (imgs, rgbs_blend, depths_blend,
+        rgbs_rig, depths_rig, rgbs_dy, depths_dy, weights_dd), each a list the caller concatenates
+        (reference networks.py:595-720).  In a torch.distributed group the chunks are split into
+        contiguous runs per rank, rendered locally and exchanged with ONE all-gather per image;
+        every list then holds a single tensor covering the image."""
+        import utils
+        import zest_parallel
+        a = self.args
+        with torch.no_grad():
+            sc = self._scene(x, bn_batch_stats=True)
+            a.img_downscale = torch.rand((1,)) * 0.75 + 0.25     # as the reference; unused by the lookup
+            N, V, C, H, W = sc['imgs'].shape
+            n_chunks = (H * W + a.chunk - 1) // a.chunk
+            world, rank = zest_parallel._world()
+            lo, hi, per = zest_parallel.shard_bounds(n_chunks, world, rank)
+            maps_only, a.zest_maps_only = getattr(a, 'zest_maps_only', False), True
+            outs = {k: [] for k in self.VAL_KEYS}
+            try:
+                for chunk_idx in range(n_chunks):
+                    self.chain_bwd = not self.chain_bwd          # every rank keeps the reference's alternation
+                    if not lo <= chunk_idx < hi:
+                        continue
+                    r = utils.build_rays_dy(
+                        sc['imgs'], x['depths'], x['w2cs'], x['c2ws'], x['intrinsics'], x['near_fars'],
+                        self.N_samples, N_rays=self.N_rays, stratified=False, pad=sc['pad'], chunk=a.chunk,
+                        idx=chunk_idx, val=True, isRandom=False, scene_flow=True, flow_fwd=x['flow_fwds'],
+                        flow_bwd=x['flow_bwds'], mask_fwd=x['mask_fwds'], mask_bwd=x['mask_bwds'])
+                    ret = self._render(sc, (r[0], r[1], r[3], r[4]), time_codes, chain_5frames=False, val=True)
+                    for k in self.VAL_KEYS:
+                        outs[k].append(ret[k].squeeze(0))
+            finally:
+                a.zest_maps_only = maps_only
+            if world > 1:
+                widths = [3, 1, 3, 1, 3, 1, 1]
+                cols = [torch.cat(outs[k]).reshape(-1, w) if outs[k] else sc['imgs'].new_zeros(0, w)
+                        for k, w in zip(self.VAL_KEYS, widths)]
+                full = zest_parallel.gather_maps(torch.cat(cols, 1), H * W, per=per * a.chunk)
+                for k, part in zip(self.VAL_KEYS, torch.split(full, widths, 1)):
+                    outs[k] = [part if part.shape[1] > 1 else part[:, 0]]
+        return (sc['imgs'],) + tuple(outs[k] for k in self.VAL_KEYS)

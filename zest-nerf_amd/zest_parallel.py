@@ -43,16 +43,18 @@ def shard_rays(rays, group=None, dim=0):
     return {k: (cut(v) if torch.is_tensor(v) else v) for k, v in rays.items()}
 
 
-def gather_maps(local_maps, n_rays, group=None, async_op=False, force=False):
+def gather_maps(local_maps, n_rays, group=None, async_op=False, force=False, per=None):
     """All-gather per-ray rows.  local_maps [r_local, C] (this rank's block, r_local <= per);
-    returns [n_rays, C] on every rank, rows in global ray order.  With async_op the collective is
+    returns [n_rays, C] on every rank, rows in global ray order.  `per`: rows per rank when the
+    blocks are not ceil(n_rays / world) (whole-image loops shard by chunks of rays).  With async_op the collective is
     only enqueued (on RCCL's own stream) and (tensor, work) is returned: call work.wait() before
     reading the tensor, so the gather of one batch overlaps the rendering of the next.
     `force` runs the collective even in a 1-rank group (rehearsal of the code path)."""
     world, rank = _world(group)
     if world == 1 and not (force and dist.is_available() and dist.is_initialized()):
         return (local_maps, None) if async_op else local_maps
-    _, _, per = shard_bounds(n_rays, world, rank)
+    if per is None:
+        _, _, per = shard_bounds(n_rays, world, rank)
     C = local_maps.shape[1]
     send = local_maps
     if local_maps.shape[0] != per:                      # last ranks of an uneven split: pad

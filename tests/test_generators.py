@@ -44,6 +44,7 @@ def _shard_worker(rank, world, port, q):
     def fake_rays(imgs, depths, w2cs, c2ws, intr, nf, S, chunk=-1, idx=-1, **kw):
         ids = torch.arange(idx * chunk, min((idx + 1) * chunk, H * W), dtype=torch.float32)
         calls.append(idx)
+        assert kw.get("zest_rays_only") is True
         return (ids[None, :, None, None].expand(1, -1, S, 3), ids[None, :, None].expand(1, -1, 3), None,
                 ids[None, :, None, None].expand(1, -1, S, 3), ids[None, :, None].expand(1, -1, S)) + (None,) * 6
 

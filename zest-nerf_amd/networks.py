@@ -82,16 +82,25 @@ class _MlpBase(nn.Module):
         raise NotImplementedError
 
     def packed(self, precision):
-        """Weights in MFMA stream order; re-packed when any parameter changes."""
-        params = dict(self.named_parameters())
-        stamp = tuple((p.data_ptr(), p._version) for p in params.values())
+        """Weights in MFMA stream order; re-packed when any parameter changes (storage or version
+        counter: optimizer steps, load_state_dict and .to() all show up).  The (name, Parameter)
+        list is cached - walking the module tree costs more host time than a 1024-ray launch."""
+        params = self.__dict__.get("_zest_params")
+        if params is None:
+            params = self.__dict__["_zest_params"] = tuple(self.named_parameters())
+        stamp = tuple((p.data_ptr(), p._version) for _, p in params)
         hit = self._packed.get(precision)
         if hit is None or hit[0] != stamp:
             desc = self._desc()
-            state = {"nerf." + k: v.detach() for k, v in params.items()}
+            state = {"nerf." + k: v.detach() for k, v in params}
             hit = (stamp, zest_hip.mlp_pack(desc, precision, zest_hip.param_table(state, desc)))
             self._packed[precision] = hit
         return hit[1]
+
+    def __setattr__(self, name, value):
+        if isinstance(value, (nn.Parameter, nn.Module)):
+            self.__dict__.pop("_zest_params", None)          # a replaced parameter / sub-module: rebuild the list
+        super().__setattr__(name, value)
 
     def zest_forward(self, x, precision=None):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
@@ -509,7 +518,8 @@ class DyMVSNeRF_G(_Generator):
                         sc['imgs'], x['depths'], x['w2cs'], x['c2ws'], x['intrinsics'], x['near_fars'],
                         self.N_samples, N_rays=self.N_rays, stratified=False, pad=sc['pad'], chunk=a.chunk,
                         idx=chunk_idx, val=True, isRandom=False, scene_flow=True, flow_fwd=x['flow_fwds'],
-                        flow_bwd=x['flow_bwds'], mask_fwd=x['mask_fwds'], mask_bwd=x['mask_bwds'])
+                        flow_bwd=x['flow_bwds'], mask_fwd=x['mask_fwds'], mask_bwd=x['mask_bwds'],
+                        zest_rays_only=True)
                     ret = self._render(sc, (r[0], r[1], r[3], r[4]), time_codes, chain_5frames=False, val=True)
                     for k in self.VAL_KEYS:
                         outs[k].append(ret[k].squeeze(0))

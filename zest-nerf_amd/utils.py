@@ -170,9 +170,11 @@ def build_rays_base(imgs, depths, w2cs, c2ws, intrinsics, near_fars, N_samples, 
                     stratified=True, pad=0, chunk=-1, idx=-1, ref_idx=0, val=False, isRandom=True,
                     patch_size=-1, scale_anneal=-1, step=0, variable_patches=False, scene_flow=False,
                     flow_fwd=None, flow_bwd=None, mask_fwd=None, mask_bwd=None, num_extra_samples=0,
-                    motion_coords=None):
+                    motion_coords=None, zest_rays_only=False):
     """Sample rays of the target (last) view and points along them; same 11-tuple as the
-    reference (utils.py:290-394)."""
+    reference (utils.py:290-394).  zest_rays_only (an addition): leave the ground-truth gathers
+    (colour, depth, flow, masks) and t_vals as None - the whole-image loops never read them and
+    they are most of the host time of a 1024-ray chunk."""
     device = imgs.device
     N, V, C, H, W = imgs.shape
     if N != 1:
@@ -188,18 +190,20 @@ def build_rays_base(imgs, depths, w2cs, c2ws, intrinsics, near_fars, N_samples, 
                              num_extra_samples=num_extra_samples, motion_coords=motion_coords)
     ys, xs = pix[0, 0].contiguous(), pix[0, 1].contiguous()
     R = xs.numel()
-    yi, xi = ys.long(), xs.long()
-    color = imgs[:, -1, :, yi, xi].permute(0, 2, 1)
-    rays_depth_gt = depths[:, -1, yi, xi]
+    color = rays_depth_gt = t_vals = None
     gt = [None, None, None, None]
-    if scene_flow:
+    if not zest_rays_only:
+        yi, xi = ys.long(), xs.long()
+        color = imgs[:, -1, :, yi, xi].permute(0, 2, 1)
+        rays_depth_gt = depths[:, -1, yi, xi]
+        t_vals = torch.linspace(0., 1., steps=N_samples).view(1, N_samples).to(device)
+    if scene_flow and not zest_rays_only:
         gt = [flow_fwd[:, -1, :, yi, xi].permute(0, 2, 1), flow_bwd[:, -1, :, yi, xi].permute(0, 2, 1),
               mask_fwd[:, -1, yi, xi], mask_bwd[:, -1, yi, xi]]
     t_rand = _draw_uniform((R, N_samples), device) if stratified else None
     d, z, pts, ndc = zest_hip.build_rays(
         xs, ys, t_rand, N_samples, intrinsics[0, -1], c2ws[0, -1], w2cs[0, ref_idx], intrinsics[0, ref_idx],
         near_fars[0, -1], near_fars[0, ref_idx], pad, W, H)
-    t_vals = torch.linspace(0., 1., steps=N_samples).view(1, N_samples).to(device)
     return (pts[None], d[None], color, ndc[None], z[None], rays_depth_gt, t_vals, gt[0], gt[1], gt[2], gt[3])
 
 
@@ -216,11 +220,13 @@ def build_rays(imgs, depths, w2cs, c2ws, intrinsics, near_fars, N_samples, N_ray
 def build_rays_dy(imgs, depths, w2cs, c2ws, intrinsics, near_fars, N_samples, N_rays=1024, stratified=True,
                   pad=0, chunk=-1, idx=-1, ref_idx=0, val=False, isRandom=True, patch_size=-1,
                   scale_anneal=-1, step=0, variable_patches=False, scene_flow=False, flow_fwd=None,
-                  flow_bwd=None, mask_fwd=None, mask_bwd=None, num_extra_samples=0, motion_coords=None):
+                  flow_bwd=None, mask_fwd=None, mask_bwd=None, num_extra_samples=0, motion_coords=None,
+                  zest_rays_only=False):
     """Reference utils.py:409-431."""
     return build_rays_base(imgs, depths, w2cs, c2ws, intrinsics, near_fars, N_samples, N_rays=N_rays,
                            stratified=stratified, pad=pad, chunk=chunk, idx=idx, ref_idx=ref_idx, val=val,
                            isRandom=isRandom, patch_size=patch_size, scale_anneal=scale_anneal, step=step,
                            variable_patches=variable_patches, scene_flow=scene_flow, flow_fwd=flow_fwd,
                            flow_bwd=flow_bwd, mask_fwd=mask_fwd, mask_bwd=mask_bwd,
-                           num_extra_samples=num_extra_samples, motion_coords=motion_coords)
+                           num_extra_samples=num_extra_samples, motion_coords=motion_coords,
+                           zest_rays_only=zest_rays_only)

@@ -44,13 +44,6 @@ constexpr int stream_units(int nt_pts, int nt_feat) {
     return (stream_units_raw(nt_pts, nt_feat) + kStreamAlign - 1) / kStreamAlign * kStreamAlign;
 }
 
-__device__ __forceinline__ f32x16 f32x16_from(const v4f b0, const v4f b1, const v4f b2, const v4f b3) {
-    f32x16 r;
-    r[0] = b0.x, r[1] = b0.y, r[2] = b0.z, r[3] = b0.w, r[4] = b1.x, r[5] = b1.y, r[6] = b1.z, r[7] = b1.w;
-    r[8] = b2.x, r[9] = b2.y, r[10] = b2.z, r[11] = b2.w, r[12] = b3.x, r[13] = b3.y, r[14] = b3.z, r[15] = b3.w;
-    return r;
-}
-
 // ---- weight source 1: global memory --------------------------------------------------------
 struct GlobalTiles {
     gptr_u4 base;          // wave-uniform: first unit of the stream

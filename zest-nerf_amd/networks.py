@@ -393,8 +393,11 @@ class _Generator(nn.Module):
                                       "(requires_grad_(False)) or run under torch.no_grad()")
         if bn_batch_stats:
             net.train()         # the reference validates with batch statistics (networks.py:629, 644)
-        with torch.no_grad():
-            return net(imgs, proj_mats, near_far, pad=self.args.pad)[0]
+        # --precision 16 (the reference runs the whole model under AMP then): library convolutions
+        # in bf16; the plane sweep and the batch norms stay fp32
+        amp = int(getattr(self.args, "precision", 32) or 32) == 16 and imgs.is_cuda
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            return net(imgs, proj_mats, near_far, pad=self.args.pad)[0].float()
 
 
 class MVSNeRF_G(_Generator):

@@ -298,7 +298,21 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
 #define ZEST_STAMP(var) do {} while (0)
 #endif
     constexpr int CB = 2 * NB;
-    for (int pass = blockIdx.x; pass < n_pass; pass += gridDim.x) {
+    // Pass order.  blockIdx % 8 labels the workgroups that share an XCD (and its L2): each label
+    // takes a contiguous run of passes, so the rays whose gathers touch neighbouring voxels and
+    // pixels (whole-image loops render contiguous pixel runs) meet in one L2 instead of being
+    // fetched into all eight.  Falls back to a plain grid stride when the grid is not a multiple of 8.
+#ifndef ZEST_NO_XCD_ORDER
+    const bool xcd_order = gridDim.x % 8 == 0;
+#else
+    const bool xcd_order = false;
+#endif
+    const int per_label = xcd_order ? (n_pass + 7) / 8 : n_pass;
+    const int pass_base = xcd_order ? (int)(blockIdx.x % 8) * per_label : 0;
+    const int pass_step = xcd_order ? (int)(gridDim.x / 8) : (int)gridDim.x;
+    for (int k = xcd_order ? (int)(blockIdx.x / 8) : (int)blockIdx.x; k < per_label; k += pass_step) {
+        const int pass = pass_base + k;
+        if (pass >= n_pass) break;
 #ifdef ZEST_STAMPS
         unsigned long long st_last = __builtin_amdgcn_s_memtime();
         st_n++;

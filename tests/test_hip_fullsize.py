@@ -35,7 +35,8 @@ def _maps(d, fused=True):
         return bench.render_step(d)
 
 
-@pytest.mark.parametrize("name", ["nsff_static_1024x128", "nsff_static_mvs_1024x128", "nsff_zest_val_1024x128"])
+@pytest.mark.parametrize("name", ["nsff_static_1024x128", "nsff_static_mvs_1024x128", "nsff_zest_val_1024x128",
+                                  "zest_val_4096x192"])          # the last: BASELINE configs[3] on one GPU
 def test_fused_equals_per_op_path_at_full_size(hip, name):
     """1024 rays x 128 samples: the one-launch fused renderer and the per-op bf16 path (encode ->
     MLP -> composite kernels, per-sample tensors in HBM) agree to bf16-operand noise, weights of

@@ -49,7 +49,9 @@ WORKLOADS = {
 }
 
 
-def build_workload(name, seed, device, rays=None):
+def build_workload(name, seed, device, rays=None, lively=True):
+    """lively: He-scale weights (O(1) activations; colours saturate) as in the bench; False: nn.Linear's
+    default scale (colours near 0.5, semi-transparent rays), the sensitive case for the PSNR check."""
     import networks
     import zest_synth as zs
     w = dict(WORKLOADS[name])
@@ -64,7 +66,7 @@ def build_workload(name, seed, device, rays=None):
                              input_ch_feat=Fd, skips=[4], net_type="v0", sceneflow=sf, static=static,
                              use_mvs=use_mvs)
         lay = zs.mlp_layout(P, 27, Fd, sf, static, use_mvs)
-        m.load_state_dict({k: torch.from_numpy(v) for k, v in zs.fill_mlp_state(lay, sd).items()})
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in zs.fill_mlp_state(lay, sd, lively=lively).items()})
         return m.to(device)
 
     G = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
@@ -115,9 +117,22 @@ def pmc_traffic(workload):
         return None
 
 
-def cpu_baseline(d, budget_s=15.0):
+def psnr_report(build_rgb, ref_rgb, seed=0):
+    """BASELINE metric 'PSNR vs ref' (SURVEY 8(d)): PSNR of the build's colours against the
+    reference's, and the north-star criterion |PSNR(build, target) - PSNR(ref, target)| against a
+    synthetic target image (reference colours + N(0, 0.05^2) noise, clipped to [0, 1])."""
+    b, r = build_rgb.double().cpu(), ref_rgb.double().cpu()
+    g = torch.Generator().manual_seed(seed)
+    target = (r + 0.05 * torch.randn(r.shape, generator=g, dtype=torch.float64)).clamp(0, 1)
+    psnr = lambda x, y: float(10.0 * torch.log10(1.0 / (x - y).square().mean().clamp_min(1e-30)))
+    return {"build_vs_ref_db": psnr(b, r), "delta_vs_target_db": abs(psnr(b, target) - psnr(r, target)),
+            "criterion_db": 0.05, "sample": "%d rays of the workload; target = reference colours + N(0, 0.05^2)" % r.shape[0]}
+
+
+def cpu_baseline(d, budget_s=15.0, build_ret=None):
     """Oracle (reference op sequence, PyTorch-CPU fp32, all host cores) on the first rays of the
-    same workload; bounded to ~budget_s seconds."""
+    same workload; bounded to ~budget_s seconds.  With build_ret (the GPU result of the same
+    batch) also returns the PSNR report of its colours against the oracle's."""
     from oracle import zest_oracle as zo
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     sc, sf = d.sc, d.cfg["scene_flow"]
@@ -138,7 +153,7 @@ def cpu_baseline(d, budget_s=15.0):
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     torch.set_num_threads(max(1, min(16, ncpu)))
     with torch.no_grad():
-        zo.rendering(*a, ns, nd, **kw)                       # warm-up
+        ref = zo.rendering(*a, ns, nd, **kw)                 # warm-up
         n, t0 = 0, time.perf_counter()
         while True:
             zo.rendering(*a, ns, nd, **kw)
@@ -146,9 +161,14 @@ def cpu_baseline(d, budget_s=15.0):
             el = time.perf_counter() - t0
             if el > budget_s or n >= 200:
                 break
-    return {"value": Rc * n / el, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d calls of %d rays x %d samples of the same workload (oracle, torch-CPU fp32, "
-                      "grid_sample/linear/cumprod op sequence of the reference)" % (n, Rc, d.S)}
+    out = {"value": Rc * n / el, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": "%d calls of %d rays x %d samples of the same workload (oracle, torch-CPU fp32, "
+                     "grid_sample/linear/cumprod op sequence of the reference)" % (n, Rc, d.S)}
+    psnr = None
+    if build_ret is not None:
+        key = "rgb_map_ref" if sf else "rgb_map"
+        psnr = psnr_report(build_ret[key][0, :Rc], ref[key].reshape(-1, 3))
+    return out, psnr
 
 
 def main():
@@ -259,7 +279,10 @@ def main():
                                  "rocprofv3 PMC passes archived in profiles/ (null if none for this workload)"},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(d, a.cpu_budget)
+            with torch.no_grad():
+                build_ret = render_step(d)
+            torch.cuda.synchronize()
+            out["cpu_baseline"], out["psnr"] = cpu_baseline(d, a.cpu_budget, build_ret)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

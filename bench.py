@@ -46,6 +46,11 @@ WORKLOADS = {
                                    note="BASELINE configs[2], inference: static + dynamic nets"),
     "zest_val_4096x192": dict(R=4096, S=192, use_mvs=True, scene_flow=True,
                               note="BASELINE configs[3] shape on one GPU"),
+    # parity-test cases (not bench lines): the other BASELINE configurations' geometry
+    "llff_static_256x64": dict(R=256, S=64, use_mvs=False, scene_flow=False, H=640, W=960, V=3, focal=800.0,
+                               note="BASELINE configs[0]: LLFF 640x960, static, use_mvs off"),
+    "dtu_static_8192x128": dict(R=8192, S=128, use_mvs=True, scene_flow=False, H=512, W=640, V=3, focal=800.0,
+                                note="BASELINE configs[4] geometry on one GPU: DTU 512x640, V=3, F=20"),
 }
 
 
@@ -56,9 +61,10 @@ def build_workload(name, seed, device, rays=None, lively=True):
     import zest_synth as zs
     w = dict(WORKLOADS[name])
     R = rays or w["R"]
-    sc = zs.make_scene(seed, R, w["S"], H=288, W=512, V=8, V_dy=4, pad=24, vol_depth=128, focal=400.0,
-                       static_volume=w["use_mvs"], dynamic=w["scene_flow"])
-    feat_dim = 8 + 4 * 8
+    V = w.get("V", 8)
+    sc = zs.make_scene(seed, R, w["S"], H=w.get("H", 288), W=w.get("W", 512), V=V, V_dy=4, pad=24, vol_depth=128,
+                       focal=w.get("focal", 400.0), static_volume=w["use_mvs"], dynamic=w["scene_flow"])
+    feat_dim = 8 + 4 * V
     sf = w["scene_flow"]
 
     def net(P, Fd, static, use_mvs, sd):
@@ -100,7 +106,7 @@ def flops_per_ray_batch(d):
     """Algorithmic MLP FLOPs of one step: 2 * sum(in*out) per sample."""
     from oracle import zest_oracle as zo
     sf = d.cfg["scene_flow"]
-    f = zo.mlp_flops_per_sample(zo.MlpSpec(63, 27, 40, sf, True, d.cfg["use_mvs"]))
+    f = zo.mlp_flops_per_sample(zo.MlpSpec(63, 27, d.args.feat_dim, sf, True, d.cfg["use_mvs"]))
     if sf:
         f += zo.mlp_flops_per_sample(zo.MlpSpec(84, 27, 24, True, False, True))
     return f * d.R * d.S, f
@@ -139,7 +145,7 @@ def cpu_baseline(d, budget_s=15.0, build_ret=None):
     Rc = min(d.R, 256)
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
     st = lambda net: {k: v.detach().cpu() for k, v in net.state_dict().items()}
-    ns = zo.Net(st(d.net_s), zo.MlpSpec(63, 27, 40, sf, True, d.cfg["use_mvs"]))
+    ns = zo.Net(st(d.net_s), zo.MlpSpec(63, 27, d.args.feat_dim, sf, True, d.cfg["use_mvs"]))
     nd = zo.Net(st(d.net_d), zo.MlpSpec(84, 27, 24, True, False, True)) if sf else None
     cams = (T(sc["w2cs"])[0], T(sc["intrinsics"])[0])
     nb = (T(sc["nb_w2cs"])[0], T(sc["nb_intrinsics"])[0]) if sf else None

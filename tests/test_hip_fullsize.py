@@ -121,3 +121,48 @@ def test_psnr_within_0p05_db_of_reference(hip, name, lively):
     assert rep["delta_vs_target_db"] <= 0.05, rep
     assert rep["build_vs_ref_db"] >= 40.0, rep          # bf16 operands: colours within ~1e-2 of fp32
     print(name, lively, rep)
+
+
+@pytest.mark.parametrize("name,rays", [("llff_static_256x64", None), ("dtu_static_8192x128", 320)])
+def test_other_baseline_configs_against_the_oracle(hip, name, rays):
+    """BASELINE configs[0] (LLFF 640x960, 256 rays x 64 samples, use_mvs off: the reference's own
+    CPU-runnable case) in full, and configs[4]'s DTU geometry (512x640, V = 3, F = 20; a 320-ray
+    subset for the CPU oracle): fp32 per-op path within 1e-4 / 1e-3 of the oracle, fused bf16
+    renderer within the bf16 tolerance and the 0.05 dB PSNR criterion."""
+    import bench
+    import renderer
+    d = _workload(name, rays=rays)
+    with torch.no_grad():
+        fused = bench.render_step(d)
+        d.args.precision, d.args.zest_maps_only = 32, False
+        full = bench.render_step(d)
+    torch.cuda.synchronize()
+    d.args.precision, d.args.zest_maps_only = 16, True
+    _, rep = bench.cpu_baseline(d, budget_s=0.0, build_ret=fused)
+    assert rep["delta_vs_target_db"] <= 0.05, rep
+    # the oracle again, all rays (cpu_baseline keeps only the first 256)
+    from oracle import zest_oracle as zo
+    sc = d.sc
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    ns = zo.Net({k: v.detach().cpu() for k, v in d.net_s.state_dict().items()},
+                zo.MlpSpec(63, 27, d.args.feat_dim, False, True, d.cfg["use_mvs"]))
+    with torch.no_grad():
+        want = zo.rendering(*[T(sc[k])[0] for k in ("rays_pts", "rays_ndc", "depth_candidates", "rays_dir")], ns, None,
+                            vol_static=T(sc["vol_static"])[0] if d.cfg["use_mvs"] else None,
+                            imgs=T(sc["imgs"])[0] if d.cfg["use_mvs"] else None,
+                            cams=(T(sc["w2cs"])[0], T(sc["intrinsics"])[0]), scene_flow=False, val=True, explicit=False)
+    for k in ("rgb_map", "depth_map"):
+        w = want[k].numpy()
+        close_most(full[k][0], torch.from_numpy(w).cuda(), 1e-4 + 1e-3 * float(np.abs(w).max()), name + "/fp32/" + k,
+                   max_bad_rays=0.0)
+        close_most(fused[k][0], torch.from_numpy(w).cuda(), 6e-2 if "depth" in k else 2e-2, name + "/fused/" + k)
+
+
+def test_dtu_geometry_full_batch_properties(hip):
+    """configs[4] at its full 8192-ray batch (1 M samples): fused == per-op bf16 path, finite, acc in [0, 1]."""
+    d = _workload("dtu_static_8192x128")
+    f, p = _maps(d, True), _maps(d, False)
+    for k in ("rgb_map", "depth_map"):
+        assert torch.isfinite(f[k]).all()
+        close_most(f[k][0], p[k][0], 4e-2 if "depth" in k else 6e-3, "dtu/" + k)
+    assert (f["acc_map"][0] >= -1e-5).all() and (f["acc_map"][0] <= 1 + 1e-4).all()

@@ -67,13 +67,14 @@ __global__ void nchw_to_nhwc_kernel(const float *__restrict__ in, int N, int C, 
 // img_feat [3V + 32, D, Hp, Wp], in_masks [V, D, Hp, Wp]
 //
 // A workgroup is one wave and owns 64 consecutive voxels.  Phase 1, one lane per voxel: the
-// homographies, bilinear weights and tap offsets are computed once per voxel and left in LDS.  Phase 2 walks the voxels 8 at a time with lane = (voxel of the octet, channel quad
-// q): a bilinear tap of a voxel is then ONE 128-byte line read by 8 neighbouring lanes, where a
-// lane-per-voxel gather touches 64 lines per load instruction and uses 16 bytes of each.  The
-// 4V + 32 output values of the 64 voxels are transposed through LDS (row stride 66 floats: the
-// quad-strided writes fall on distinct banks up to a free 2-way) so every output plane
-// receives 256 contiguous bytes.  Geometry and transpose tile are separate LDS arrays, so the
-// eight octets are independent for the compiler and their loads overlap.
+// homographies, bilinear weights and tap offsets are computed once per voxel and left in LDS.
+// Phase 2 walks the voxels 16 at a time with lane = (voxel of the group, channel octet h): a
+// bilinear tap of a voxel is then one 128-byte line read by 4 neighbouring lanes (two 16-byte
+// loads each, one 32-bit offset per tap), where a lane-per-voxel gather touches 64 lines per
+// load instruction and uses 16 bytes of each.  The 4V + 32 output values of the 64 voxels are
+// transposed through LDS (row stride 66 floats) so every output plane receives 256 contiguous
+// bytes, written with streaming stores.  Geometry and transpose tile are separate LDS arrays, so
+// the four groups are independent for the compiler and their loads overlap.
 constexpr int kRowStride = 66;
 constexpr int kMaxViews = 8;
 
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(64) void volume_cost_kernel(
     __shared__ float4 vox[64];          // ref pixel offset (-1: ring, -2: past the end), 1/count, in-frame bit mask
     const int Hp = H + 2 * pad, Wp = W + 2 * pad;
     const long long nvox = (long long)D * Hp * Wp;
-    const int lane = threadIdx.x, vsub = lane >> 3, q = lane & 7;
+    const int lane = threadIdx.x;
     const long long base = (long long)blockIdx.x * 64;
     {   // ---- phase 1: lane = voxel
         const long long idx = base + lane;
@@ -118,72 +119,87 @@ __global__ __launch_bounds__(64) void volume_cost_kernel(
                                 __int_as_float(in_frame), 0.0f);
     }
     __syncthreads();
-    // ---- phase 2: lane = (voxel of the octet, channel quad).  Branch-free, so the eight octets
-    // form one basic block and the compiler keeps the loads of several of them in flight
-    // (voxels past the end of the volume compute on clamped addresses and are dropped at the
-    // final store).
+    // ---- phase 2: lane = (voxel of a group of 16, channel octet h).  Branch-free, so the four
+    // groups form one basic block and the compiler keeps their loads in flight together (voxels
+    // past the end of the volume compute on clamped addresses and are dropped at the final
+    // store).  One 32-bit byte offset per tap; the octet's two 16-byte halves differ by an
+    // immediate.
+    const int v16 = lane >> 2, h = lane & 3;
+    const char *fbase = reinterpret_cast<const char *>(feats);
 #pragma unroll
-    for (int it = 0; it < 8; it++) {
-        const int v = it * 8 + vsub;
+    for (int it = 0; it < 4; it++) {
+        const int v = it * 16 + v16;
         const float4 g = vox[v];
         const int ref_off = __float_as_int(g.x);
         const bool has_ref = ref_off >= 0;
         // reference view: its own feature map, zero in the padding ring
-        const float4 rf = feats[(size_t)(has_ref ? ref_off : 0) * (kC / 4) + q];
-        float4 sum = has_ref ? rf : make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 sq = make_float4(sum.x * sum.x, sum.y * sum.y, sum.z * sum.z, sum.w * sum.w);
+        float4 sum[2], sq[2];
+        {
+            const unsigned bo = (unsigned)(has_ref ? ref_off : 0) * 128u + (unsigned)h * 32u;
+            const float4 r0 = *reinterpret_cast<const float4 *>(fbase + bo);
+            const float4 r1 = *reinterpret_cast<const float4 *>(fbase + bo + 16);
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            sum[0] = has_ref ? r0 : z4, sum[1] = has_ref ? r1 : z4;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+            sq[j] = make_float4(sum[j].x * sum[j].x, sum[j].y * sum[j].y, sum[j].z * sum[j].z, sum[j].w * sum[j].w);
 #pragma unroll
         for (int i = 1; i < V; i++) {
             const int4 o4 = toff[(i - 1) * 64 + v];
             const float4 w4 = tw[(i - 1) * 64 + v];
-            const float4 *f = feats + (size_t)i * H * W * (kC / 4);
-#ifdef ZEST_EXPERIMENT_NO_GATHER       // timing experiment only
-            const float4 t0 = w4, t1 = w4, t2 = w4, t3 = w4;
-#else
-            const float4 t0 = f[(size_t)o4.x * (kC / 4) + q], t1 = f[(size_t)o4.y * (kC / 4) + q],
-                         t2 = f[(size_t)o4.z * (kC / 4) + q], t3 = f[(size_t)o4.w * (kC / 4) + q];
-#endif
-            float4 a;
-            a.x = fmaf(w4.w, t3.x, fmaf(w4.z, t2.x, fmaf(w4.y, t1.x, w4.x * t0.x)));
-            a.y = fmaf(w4.w, t3.y, fmaf(w4.z, t2.y, fmaf(w4.y, t1.y, w4.x * t0.y)));
-            a.z = fmaf(w4.w, t3.z, fmaf(w4.z, t2.z, fmaf(w4.y, t1.z, w4.x * t0.z)));
-            a.w = fmaf(w4.w, t3.w, fmaf(w4.z, t2.w, fmaf(w4.y, t1.w, w4.x * t0.w)));
-            sum.x += a.x, sum.y += a.y, sum.z += a.z, sum.w += a.w;
-            sq.x = fmaf(a.x, a.x, sq.x), sq.y = fmaf(a.y, a.y, sq.y), sq.z = fmaf(a.z, a.z, sq.z), sq.w = fmaf(a.w, a.w, sq.w);
-        }
-        // images: the octet's 8 lanes take one bilinear tap each - lanes 4j .. 4j+3 the four taps of
-        // one view - and add them up with two quad shuffles; rounds of two views
+            const unsigned view_b = (unsigned)i * (unsigned)(H * W) * 128u + (unsigned)h * 32u;
+            const unsigned b0 = view_b + (unsigned)o4.x * 128u, b1 = view_b + (unsigned)o4.y * 128u,
+                           b2 = view_b + (unsigned)o4.z * 128u, b3 = view_b + (unsigned)o4.w * 128u;
 #pragma unroll
-        for (int i0 = 0; i0 < V; i0 += 2) {
-            const int iv = i0 + (q >> 2), c = q & 3;            // view of this lane, tap of this lane
-            const bool ok = iv < V;
-            const int ivc = ok ? iv : 0;
-            // view 0 is the reference image itself (one tap of weight 1, zero in the padding ring);
-            // lanes beyond the last view read view 1's entry with weight 0
-            const int vi = (ok && ivc > 0) ? ivc - 1 : 0;      // index into the per-source-view geometry
-            const int4 o4 = toff[vi * 64 + v];
-            const float4 w4 = tw[vi * 64 + v];
-            const int off = ivc == 0 ? (has_ref ? ref_off : 0) : (c == 0 ? o4.x : c == 1 ? o4.y : c == 2 ? o4.z : o4.w);
-            const float wsel = c == 0 ? w4.x : c == 1 ? w4.y : c == 2 ? w4.z : w4.w;
-            const float wgt = !ok ? 0.0f : (ivc == 0 ? ((has_ref && c == 0) ? 1.0f : 0.0f) : wsel);
-            const float4 tv = imgs[(size_t)ivc * H * W + off];
+            for (int j = 0; j < 2; j++) {
+#ifdef ZEST_EXPERIMENT_NO_GATHER       // timing experiment only
+                const float4 t0 = w4, t1 = w4, t2 = w4, t3 = w4;
+#else
+                const float4 t0 = *reinterpret_cast<const float4 *>(fbase + b0 + 16 * j),
+                             t1 = *reinterpret_cast<const float4 *>(fbase + b1 + 16 * j),
+                             t2 = *reinterpret_cast<const float4 *>(fbase + b2 + 16 * j),
+                             t3 = *reinterpret_cast<const float4 *>(fbase + b3 + 16 * j);
+#endif
+                float4 a;
+                a.x = fmaf(w4.w, t3.x, fmaf(w4.z, t2.x, fmaf(w4.y, t1.x, w4.x * t0.x)));
+                a.y = fmaf(w4.w, t3.y, fmaf(w4.z, t2.y, fmaf(w4.y, t1.y, w4.x * t0.y)));
+                a.z = fmaf(w4.w, t3.z, fmaf(w4.z, t2.z, fmaf(w4.y, t1.z, w4.x * t0.z)));
+                a.w = fmaf(w4.w, t3.w, fmaf(w4.z, t2.w, fmaf(w4.y, t1.w, w4.x * t0.w)));
+                sum[j].x += a.x, sum[j].y += a.y, sum[j].z += a.z, sum[j].w += a.w;
+                sq[j].x = fmaf(a.x, a.x, sq[j].x), sq[j].y = fmaf(a.y, a.y, sq[j].y);
+                sq[j].z = fmaf(a.z, a.z, sq[j].z), sq[j].w = fmaf(a.w, a.w, sq[j].w);
+            }
+            // image of this view: lane h takes tap h, two quad shuffles add the four up
+            const int off = h == 0 ? o4.x : h == 1 ? o4.y : h == 2 ? o4.z : o4.w;
+            const float wgt = h == 0 ? w4.x : h == 1 ? w4.y : h == 2 ? w4.z : w4.w;
+            const float4 tv = imgs[(size_t)i * H * W + off];
             float bx = wgt * tv.x, by = wgt * tv.y, bz = wgt * tv.z;
             bx += __shfl_xor(bx, 1, 64), by += __shfl_xor(by, 1, 64), bz += __shfl_xor(bz, 1, 64);
             bx += __shfl_xor(bx, 2, 64), by += __shfl_xor(by, 2, 64), bz += __shfl_xor(bz, 2, 64);
-            if (c == 0 && ok) {
-                // the reference leaves channels 0-2 of the padding ring uninitialised (torch.empty); 0 here
-                tile[(3 * iv) * kRowStride + v] = bx, tile[(3 * iv + 1) * kRowStride + v] = by;
-                tile[(3 * iv + 2) * kRowStride + v] = bz;
-                tile[(3 * V + kC + iv) * kRowStride + v] = ((__float_as_int(g.z) >> iv) & 1) ? 1.0f : 0.0f;
+            if (h == 0) {
+                tile[(3 * i) * kRowStride + v] = bx, tile[(3 * i + 1) * kRowStride + v] = by;
+                tile[(3 * i + 2) * kRowStride + v] = bz;
+                tile[(3 * V + kC + i) * kRowStride + v] = ((__float_as_int(g.z) >> i) & 1) ? 1.0f : 0.0f;
             }
         }
+        if (h == 0) {
+            // the reference leaves channels 0-2 of the padding ring uninitialised (torch.empty); 0 here
+            const float4 c0 = imgs[has_ref ? ref_off : 0];
+            tile[0 * kRowStride + v] = has_ref ? c0.x : 0.f, tile[1 * kRowStride + v] = has_ref ? c0.y : 0.f;
+            tile[2 * kRowStride + v] = has_ref ? c0.z : 0.f;
+            tile[(3 * V + kC) * kRowStride + v] = 1.0f;
+        }
         const float inv = g.y;
-        float *o = tile + (size_t)(3 * V + 4 * q) * kRowStride + v;
-        float mean = sum.x * inv;
-        o[0] = sq.x * inv - mean * mean;
-        mean = sum.y * inv, o[kRowStride] = sq.y * inv - mean * mean;
-        mean = sum.z * inv, o[2 * kRowStride] = sq.z * inv - mean * mean;
-        mean = sum.w * inv, o[3 * kRowStride] = sq.w * inv - mean * mean;
+        float *o = tile + (size_t)(3 * V + 8 * h) * kRowStride + v;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            float mean = sum[j].x * inv;
+            o[(4 * j) * kRowStride] = sq[j].x * inv - mean * mean;
+            mean = sum[j].y * inv, o[(4 * j + 1) * kRowStride] = sq[j].y * inv - mean * mean;
+            mean = sum[j].z * inv, o[(4 * j + 2) * kRowStride] = sq[j].z * inv - mean * mean;
+            mean = sum[j].w * inv, o[(4 * j + 3) * kRowStride] = sq[j].w * inv - mean * mean;
+        }
     }
     __syncthreads();
     const long long idx = base + lane;
@@ -250,6 +266,8 @@ extern "C" int zest_volume_cost_fwd(const float *feats_cl, const float *imgs_cl,
     ZEST_CHECK_ARG(V <= kMaxViews, "zest_volume_cost_fwd: at most %d views (LDS transpose tile), got %d", kMaxViews, V);
     const long long nvox = (long long)D * (H + 2 * pad) * (W + 2 * pad);
     ZEST_CHECK_ARG(nvox < (1ll << 31), "zest_volume_cost_fwd: %lld voxels exceed the 32-bit index range", nvox);
+    ZEST_CHECK_ARG((long long)V * H * W * 128 < (1ll << 32), "zest_volume_cost_fwd: feature maps of %d x %d x %d "
+                   "pixels exceed the 32-bit byte offsets of the gather", V, H, W);
 #define ZEST_SWEEP(VT)                                                                               \
     hipLaunchKernelGGL(volume_cost_kernel<VT>, dim3(zest_div_up(nvox, 64)), dim3(64), 0,                 \
                        (hipStream_t)stream, (const float4 *)feats_cl, (const float4 *)imgs_cl, proj, depth, \

@@ -28,7 +28,7 @@ extern "C" {
 
 /* arithmetic of the MLP contraction */
 #define ZEST_PREC_F32  0   /* v_mfma_f32_32x32x2_f32: exact fp32 products, parity mode */
-#define ZEST_PREC_BF16 1   /* v_mfma_f32_32x32x16_bf16: bf16 operands, fp32 accumulate  */
+#define ZEST_PREC_BF16 1   /* v_mfma_f32_16x16x32_bf16: bf16 operands, fp32 accumulate  */
 
 /* extra heads of the MLP (reference networks.py:115-123) */
 #define ZEST_HEAD_NONE    0  /* out = rgb(3) sigma(1)                                     */
@@ -253,8 +253,10 @@ int zest_mlp_fwd(const zest_mlp_desc *desc, int precision, const void *packed,
 
 /* ---- fused inference path ---------------------------------------------------------
  * rendering(..., val=True) (reference renderer.py:579-626 with the early return at
- * :444-445) in two launches: encode + feature gathers + static MLP [+ dynamic MLP] +
- * per-block compositing (nothing per-sample written to HBM), then a per-ray combine.
+ * :444-445): encode + feature gathers + static MLP [+ dynamic MLP] + per-block compositing
+ * in one launch, nothing per-sample written to HBM.  The 32-sample blocks of a ray are chained
+ * inside that launch when 8 blocks hold whole rays (S <= 32, 64, 128, 256), otherwise by a
+ * second tiny launch reading the block records from `workspace`.
  * out [R,16]: 0-2 rgb_map, 3 depth_map, 4 acc_map; with the dynamic net also
  * 5-7 rgb_map_ref, 8 depth_map_ref, 9-11 rgb_map_ref_dy, 12 depth_map_ref_dy,
  * 13 weights_map_dd; 14,15 reserved. */

@@ -68,7 +68,7 @@ def main():
         from oracle import zest_oracle as zo
         fl = zo.mlp_flops_per_sample(zo.MlpSpec(63, 27, 40, False, True, True)) * M
         for prec, name, peak in ((zest_hip.PREC_F32, "mlp fp32 (32x32x2 f32 MFMA)", F32_MFMA_PEAK),
-                                 (zest_hip.PREC_BF16, "mlp bf16 standalone (global-memory weights)", BF16_PEAK)):
+                                 (zest_hip.PREC_BF16, "mlp bf16 standalone (x rows in HBM -> LDS-ring engine)", BF16_PEAK)):
             packed = d.net_s.packed(prec)
             t = timeit(lambda: zest_hip.mlp_fwd(desc, prec, packed, x), n=20)
             report(name, t, flops=fl, peak=peak, unit="TFLOP/s")

@@ -1,6 +1,9 @@
 // Standalone bf16 MLP forward (zest_mlp_fwd, ZEST_PREC_BF16): x [M,C_in] fp32 in HBM ->
 // operand registers -> engine -> out [M,C_out].  Backs MVSNeRF.forward in bf16 mode and the
-// MFMA-utilisation measurement of the MLP alone.
+// MFMA-utilisation measurement of the MLP alone.  Same structure as the fused renderer: 8 waves
+// per workgroup share the weight stream through the LDS ring (LDS-DMA), each wave carries 32
+// rows through the network in registers; only the operand source (rows of x instead of the
+// in-kernel encoders) and the sink (raw network outputs instead of compositing) differ.
 #include "mlp_engine.cuh"
 
 namespace zest {
@@ -34,58 +37,82 @@ __device__ __forceinline__ void load_operand(const float *__restrict__ xrow, boo
 }
 
 // A wave runs NB blocks of 32 rows = 2 NB column blocks of 16 (lane: column l & 15, group l >> 4).
+constexpr int kMlpWaves = 8;
+
 template <int NB, int NT_PTS, bool MOD, int NT_FEAT>
-__global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void mlp_bf16_kernel(
-    PosMaps maps, const uint4 *__restrict__ tiles, const float *__restrict__ x, int M, int P, int F, int C_in, int C_out, int head, int v2,
+__global__ __launch_bounds__(kMlpWaves * 64, kMlpWaves / 4) void mlp_bf16_kernel(
+    PosMaps maps, const uint4 *__restrict__ tiles_g, const float *__restrict__ x, int M, int P, int F, int C_in, int C_out, int head, int v2,
     float *__restrict__ out) {
-    constexpr int CB = 2 * NB;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int col = lane & 15, grp = lane >> 4;
-    const long long m_base = ((long long)blockIdx.x * 4 + wave) * (32 * NB);
-    if (m_base >= M) return;                       // wave-uniform
-    OpArr<NT_PTS / 2> pts[CB];
-    OpArr<NT_FEAT / 2> feat[CB];
-#pragma unroll
-    for (int cb = 0; cb < CB; cb++) {
-        const long long m = m_base + 16 * cb + col;
-        const bool valid = m < M;
-        const float *xrow = x + (size_t)(valid ? m : 0) * C_in;
-        load_operand<NT_PTS / 2>(xrow, valid, grp, maps.pts, pts[cb]);
-        if (MOD) load_operand<NT_FEAT / 2>(xrow + P, valid, grp, maps.feat, feat[cb]);
-    }
-    auto views_fn = [&](OpArr<1> (&views)[CB]) {
+    constexpr int CB = 2 * NB, UNITS = stream_units(NT_PTS, MOD ? NT_FEAT : 0);
+    using Ring = RingTiles<kMlpWaves, UNITS, 0>;
+    __shared__ __attribute__((aligned(16))) char lds[kRingUnits * 1024 + 2 * kSlots * 4];
+#ifdef ZEST_RING_FLAGS
+    int *ring_flags = reinterpret_cast<int *>(lds + kRingUnits * 1024);
+    Ring::init_flags(ring_flags);
+    __syncthreads();
+#endif
+    const int lane = threadIdx.x & 63, col = lane & 15, grp = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const Ring tiles{lds, (gptr_u4)tiles_g, (gptr_u4)tiles_g, lane, grp, wave,
+                     (unsigned)(wave * Ring::kPieces * 64 + lane) * 16u,
+                     (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds +
+                         (unsigned)wave * Ring::kPieces * 1024u
+#ifdef ZEST_RING_FLAGS
+                     , (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)ring_flags
+#endif
+    };
+    tiles.init_addr();
+    tiles.prologue();
+    const int n_blocks = (M + 32 * NB - 1) / (32 * NB), n_pass = (n_blocks + kMlpWaves - 1) / kMlpWaves;
+    for (int pass = blockIdx.x; pass < n_pass; pass += gridDim.x) {
+        // every wave walks the stream in step, also one whose rows lie past M (its loads are
+        // clamped and its stores masked)
+        const long long m_base = ((long long)pass * kMlpWaves + wave) * (32 * NB);
+        OpArr<NT_PTS / 2> pts[CB];
+        OpArr<NT_FEAT / 2> feat[CB];
 #pragma unroll
         for (int cb = 0; cb < CB; cb++) {
             const long long m = m_base + 16 * cb + col;
             const bool valid = m < M;
-            load_operand<1>(x + (size_t)(valid ? m : 0) * C_in + P + F, valid, grp, maps.views, views[cb]);
+            const float *xrow = x + (size_t)(valid ? m : 0) * C_in;
+            load_operand<NT_PTS / 2>(xrow, valid, grp, maps.pts, pts[cb]);
+            if (MOD) load_operand<NT_FEAT / 2>(xrow + P, valid, grp, maps.feat, feat[cb]);
         }
-    };
-    f32x4 headt[CB], rgbt[CB];
-    GlobalTiles gt{(gptr_u4)tiles, lane, grp};
-    int unit = 0;
-    engine_forward<NB, NT_PTS, MOD, NT_FEAT>(gt, unit, v2 != 0, pts, feat, views_fn, headt, rgbt);
+        auto views_fn = [&](OpArr<1> (&views)[CB]) {
 #pragma unroll
-    for (int cb = 0; cb < CB; cb++) {
-        const long long m = m_base + 16 * cb + col;
-        if (m >= M) continue;
-        float *o = out + (size_t)m * C_out;
-        // tile row r sits in lane group r >> 2, element r & 3
-        if (grp == 0) {
-            o[0] = v2 ? zest_sigmoid(rgbt[cb][0]) : rgbt[cb][0];
-            o[1] = v2 ? zest_sigmoid(rgbt[cb][1]) : rgbt[cb][1];
-            o[2] = v2 ? zest_sigmoid(rgbt[cb][2]) : rgbt[cb][2];
-            o[3] = v2 ? fmaxf(headt[cb][0], 0.0f) : headt[cb][0];
-            if (head == ZEST_HEAD_BLEND) o[4] = zest_sigmoid(headt[cb][1]);
-            if (head == ZEST_HEAD_DYNAMIC)
-                o[4] = tanhf(headt[cb][1]), o[5] = tanhf(headt[cb][2]), o[6] = tanhf(headt[cb][3]);   // rows 1-3
-        } else if (head == ZEST_HEAD_DYNAMIC && grp == 1) {
-            o[7] = tanhf(headt[cb][0]), o[8] = tanhf(headt[cb][1]), o[9] = tanhf(headt[cb][2]);      // rows 4-6
-            o[10] = zest_sigmoid(headt[cb][3]);                                                      // row 7
-        } else if (head == ZEST_HEAD_DYNAMIC && grp == 2) {
-            o[11] = zest_sigmoid(headt[cb][0]);                                                      // row 8
+            for (int cb = 0; cb < CB; cb++) {
+                const long long m = m_base + 16 * cb + col;
+                const bool valid = m < M;
+                load_operand<1>(x + (size_t)(valid ? m : 0) * C_in + P + F, valid, grp, maps.views, views[cb]);
+            }
+        };
+        f32x4 headt[CB], rgbt[CB];
+        int unit = 0;
+        engine_forward<NB, NT_PTS, MOD, NT_FEAT>(tiles, unit, v2 != 0, pts, feat, views_fn, headt, rgbt);
+#pragma unroll
+        for (int cb = 0; cb < CB; cb++) {
+            const long long m = m_base + 16 * cb + col;
+            if (m >= M) continue;
+            float *o = out + (size_t)m * C_out;
+            // tile row r sits in lane group r >> 2, element r & 3
+            if (grp == 0) {
+                o[0] = v2 ? zest_sigmoid(rgbt[cb][0]) : rgbt[cb][0];
+                o[1] = v2 ? zest_sigmoid(rgbt[cb][1]) : rgbt[cb][1];
+                o[2] = v2 ? zest_sigmoid(rgbt[cb][2]) : rgbt[cb][2];
+                o[3] = v2 ? fmaxf(headt[cb][0], 0.0f) : headt[cb][0];
+                if (head == ZEST_HEAD_BLEND) o[4] = zest_sigmoid(headt[cb][1]);
+                if (head == ZEST_HEAD_DYNAMIC)
+                    o[4] = tanhf(headt[cb][1]), o[5] = tanhf(headt[cb][2]), o[6] = tanhf(headt[cb][3]);   // rows 1-3
+            } else if (head == ZEST_HEAD_DYNAMIC && grp == 1) {
+                o[7] = tanhf(headt[cb][0]), o[8] = tanhf(headt[cb][1]), o[9] = tanhf(headt[cb][2]);      // rows 4-6
+                o[10] = zest_sigmoid(headt[cb][3]);                                                      // row 7
+            } else if (head == ZEST_HEAD_DYNAMIC && grp == 2) {
+                o[11] = zest_sigmoid(headt[cb][0]);                                                      // row 8
+            }
         }
+        tiles.next_pass();
     }
+    tiles.drain();
 }
 
 template <int NB, int NT_PTS, bool MOD, int NT_FEAT>
@@ -100,8 +127,13 @@ static int launch_one(const MlpPlan &p, const PosMaps &maps, const void *tiles, 
     const int F = d.use_feat ? d.in_ch_feat : 0;
     const int C_in = d.in_ch_pts + F + d.in_ch_views;
     const int C_out = d.head == ZEST_HEAD_NONE ? 4 : (d.head == ZEST_HEAD_BLEND ? 5 : 12);
-    const int blocks = zest_div_up(M, 4 * 32 * NB);
-    hipLaunchKernelGGL((mlp_bf16_kernel<NB, NT_PTS, MOD, NT_FEAT>), dim3(blocks), dim3(256), 0, stream,
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        cus = 256;
+    const int n_pass = zest_div_up(zest_div_up(M, 32 * NB), kMlpWaves);
+    const int blocks = n_pass < cus ? n_pass : cus;             // one workgroup per CU (128 KiB ring)
+    hipLaunchKernelGGL((mlp_bf16_kernel<NB, NT_PTS, MOD, NT_FEAT>), dim3(blocks), dim3(kMlpWaves * 64), 0, stream,
                        maps, (const uint4 *)tiles, x, M, d.in_ch_pts, F, C_in, C_out, d.head,
                        d.net_type == 2 ? 1 : 0, out);
     ZEST_RETURN_LAUNCH("zest_mlp_fwd(bf16)");

@@ -16,9 +16,10 @@
 // to the 64-register input and output operands.
 //
 // The weight stream (units of 1 KiB in consumption order, mlp_plan.h) comes from a `Tiles`
-// source: GlobalTiles reads units straight from global memory (standalone MLP kernel);
-// RingTiles (fused renderer) reads them from an LDS ring that the workgroup's waves keep
-// filled with LDS-DMA (`global_load_lds`), several chunks ahead of the MFMAs.
+// source: RingTiles (fused renderer and standalone MLP kernel) reads them from an LDS ring that
+// the workgroup's waves keep filled with LDS-DMA (`global_load_lds`), several chunks ahead of
+// the MFMAs.  (Reading every unit from global memory in every wave, the first version of the
+// standalone kernel, is 2.3x slower.)
 #pragma once
 #include <hip/hip_bf16.h>
 #include "mlp_plan.h"
@@ -44,25 +45,7 @@ constexpr int stream_units(int nt_pts, int nt_feat) {
     return (stream_units_raw(nt_pts, nt_feat) + kStreamAlign - 1) / kStreamAlign * kStreamAlign;
 }
 
-// ---- weight source 1: global memory --------------------------------------------------------
-struct GlobalTiles {
-    gptr_u4 base;          // wave-uniform: first unit of the stream
-    int lane, grp;         // grp = lane >> 4
-    __device__ __forceinline__ bf16x8 load(int unit) const {
-        const v4u v = base[(size_t)unit * 64 + lane];
-        return *reinterpret_cast<const bf16x8 *>(&v);
-    }
-    // bias block `which` (0 = op bias, 1 = modulation bias) of header unit `unit`: the four
-    // biases of this lane's accumulator rows 16 rt + 4 grp .. + 3
-    __device__ __forceinline__ f32x4 load_bias(int unit, int which, int rt) const {
-        const __attribute__((address_space(1))) v4f *b =
-            (const __attribute__((address_space(1))) v4f *)(base + (size_t)unit * 64) + which * 8 + rt * 4 + grp;
-        return *b;
-    }
-    __device__ __forceinline__ void finish(int, int) const {}
-};
-
-// ---- weight source 2: LDS ring fed by LDS-DMA -----------------------------------------------
+// ---- weight source: LDS ring fed by LDS-DMA -----------------------------------------------
 // The ring holds kRingUnits KiB = kSlots chunks of kChunk units.  All NW waves of the
 // workgroup walk the stream in step.  On entering chunk c every wave waits until its own DMA
 // pieces of chunk c have landed (counted vmcnt: the younger kAhead-1 chunks stay in flight),

@@ -8,30 +8,52 @@
 
 namespace zest {
 
-struct PosMaps {             // feature index per operand position (kt*32 + 8*grp + e), -1 = zero pad
-    short pts[96];
-    short feat[64];
-    short views[32];
-};
-
-// k-tiles of one column block's operand from its sample's input row
-template <int NK>
-__device__ __forceinline__ void load_operand(const float *__restrict__ xrow, bool valid, int grp,
-                                             const short *map, OpArr<NK> &op) {
+// Operand assembly.  The position -> input-column maps of the plan (mlp_plan.hip pe_map_acc,
+// feat_map_acc) are affine in the lane group, so a lane needs one row pointer per operand and
+// compile-time offsets - no table lookups, no per-element address arithmetic:
+//   PE operand of C coordinates, L bands: element e of k-tile kt is m = 8 kt + e;
+//     m < (L/2) C:  column C + 2C (2 (m / C) + (g >> 1)) + (g & 1) C + m % C
+//                   = [C + 4C (m / C) + m % C] + [(g >> 1) 2C + (g & 1) C];   m = (L/2) C: column g (< C)
+//   feature operand: quad q = 8 kt + 2 g + (e >> 2), channel c = e & 3:
+//     q = 0, 2: volume columns c, 4 + c;  q = 1, 3: columns 8 + c, 12 + c;  q >= 4: column 4 q + c
+template <int C, int L, int NK>
+__device__ __forceinline__ void load_pe_operand(const float *__restrict__ xrow, bool valid, int grp, OpArr<NK> &op) {
+    const float *xg = xrow + (grp >> 1) * 2 * C + (grp & 1) * C;
+    const float raw = (valid && grp < C) ? xrow[grp < C ? grp : 0] : 0.0f;
 #pragma unroll
     for (int t = 0; t < NK; t++) {
-        unsigned w[4];
+        float v[8];
 #pragma unroll
-        for (int jj = 0; jj < 4; jj++) {
-            float v[2];
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const int idx = map[32 * t + 8 * grp + 2 * jj + u];
-                v[u] = (valid && idx >= 0) ? xrow[idx < 0 ? 0 : idx] : 0.0f;
-            }
-            w[jj] = pack_bf16(v[0], v[1]);
+        for (int e = 0; e < 8; e++) {
+            const int m = 8 * t + e;
+            if (m < (L / 2) * C)
+                v[e] = valid ? xg[C + 4 * C * (m / C) + m % C] : 0.0f;
+            else
+                v[e] = m == (L / 2) * C ? raw : 0.0f;
         }
-        uint4 a = make_uint4(w[0], w[1], w[2], w[3]);
+        uint4 a = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+        op.t[t] = *reinterpret_cast<bf16x8 *>(&a);
+    }
+}
+
+template <int NK>
+__device__ __forceinline__ void load_feat_operand(const float *__restrict__ xf, int F, bool valid, int grp, OpArr<NK> &op) {
+#pragma unroll
+    for (int t = 0; t < NK; t++) {
+        // first columns of this lane's two quads
+        int ca, cb;
+        if (t == 0) {
+            ca = grp == 0 ? 0 : (grp == 1 ? 4 : 8 * grp);              // quads 0, 2, 4, 6
+            cb = grp == 0 ? 8 : (grp == 1 ? 12 : 8 * grp + 4);         // quads 1, 3, 5, 7
+        } else {
+            ca = 32 * t + 8 * grp, cb = ca + 4;
+        }
+        const bool va = valid && ca + 4 <= F, vb = valid && cb + 4 <= F;
+        const float *pa = xf + (va ? ca : 0), *pb = xf + (vb ? cb : 0);
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 4; c++) v[c] = va ? pa[c] : 0.0f, v[4 + c] = vb ? pb[c] : 0.0f;
+        uint4 a = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
         op.t[t] = *reinterpret_cast<bf16x8 *>(&a);
     }
 }
@@ -41,7 +63,7 @@ constexpr int kMlpWaves = 8;
 
 template <int NB, int NT_PTS, bool MOD, int NT_FEAT>
 __global__ __launch_bounds__(kMlpWaves * 64, kMlpWaves / 4) void mlp_bf16_kernel(
-    PosMaps maps, const uint4 *__restrict__ tiles_g, const float *__restrict__ x, int M, int P, int F, int C_in, int C_out, int head, int v2,
+    const uint4 *__restrict__ tiles_g, const float *__restrict__ x, int M, int P, int F, int C_in, int C_out, int head, int v2,
     float *__restrict__ out) {
     constexpr int CB = 2 * NB, UNITS = stream_units(NT_PTS, MOD ? NT_FEAT : 0);
     using Ring = RingTiles<kMlpWaves, UNITS, 0>;
@@ -75,15 +97,15 @@ __global__ __launch_bounds__(kMlpWaves * 64, kMlpWaves / 4) void mlp_bf16_kernel
             const long long m = m_base + 16 * cb + col;
             const bool valid = m < M;
             const float *xrow = x + (size_t)(valid ? m : 0) * C_in;
-            load_operand<NT_PTS / 2>(xrow, valid, grp, maps.pts, pts[cb]);
-            if (MOD) load_operand<NT_FEAT / 2>(xrow + P, valid, grp, maps.feat, feat[cb]);
+            load_pe_operand<NT_PTS == 4 ? 3 : 4, 10, NT_PTS / 2>(xrow, valid, grp, pts[cb]);
+            if (MOD) load_feat_operand<NT_FEAT / 2>(xrow + P, F, valid, grp, feat[cb]);
         }
         auto views_fn = [&](OpArr<1> (&views)[CB]) {
 #pragma unroll
             for (int cb = 0; cb < CB; cb++) {
                 const long long m = m_base + 16 * cb + col;
                 const bool valid = m < M;
-                load_operand<1>(x + (size_t)(valid ? m : 0) * C_in + P + F, valid, grp, maps.views, views[cb]);
+                load_pe_operand<3, 4, 1>(x + (size_t)(valid ? m : 0) * C_in + P + F, valid, grp, views[cb]);
             }
         };
         f32x4 headt[CB], rgbt[CB];
@@ -116,7 +138,7 @@ __global__ __launch_bounds__(kMlpWaves * 64, kMlpWaves / 4) void mlp_bf16_kernel
 }
 
 template <int NB, int NT_PTS, bool MOD, int NT_FEAT>
-static int launch_one(const MlpPlan &p, const PosMaps &maps, const void *tiles, const float *x, int M,
+static int launch_one(const MlpPlan &p, const void *tiles, const float *x, int M,
                       float *out, hipStream_t stream) {
     if (p.n_tiles != stream_units(NT_PTS, MOD ? NT_FEAT : 0)) {
         zest_set_error("zest_mlp_fwd(bf16): plan has %d stream units, kernel expects %d", p.n_tiles,
@@ -134,34 +156,22 @@ static int launch_one(const MlpPlan &p, const PosMaps &maps, const void *tiles, 
     const int n_pass = zest_div_up(zest_div_up(M, 32 * NB), kMlpWaves);
     const int blocks = n_pass < cus ? n_pass : cus;             // one workgroup per CU (128 KiB ring)
     hipLaunchKernelGGL((mlp_bf16_kernel<NB, NT_PTS, MOD, NT_FEAT>), dim3(blocks), dim3(kMlpWaves * 64), 0, stream,
-                       maps, (const uint4 *)tiles, x, M, d.in_ch_pts, F, C_in, C_out, d.head,
+                       (const uint4 *)tiles, x, M, d.in_ch_pts, F, C_in, C_out, d.head,
                        d.net_type == 2 ? 1 : 0, out);
     ZEST_RETURN_LAUNCH("zest_mlp_fwd(bf16)");
 }
 
 int mlp_bf16_launch(const MlpPlan &p, const void *tiles, const float *x, int M, float *out,
                     hipStream_t stream) {
-    PosMaps maps;
-    for (auto &r : maps.pts) r = -1;
-    for (auto &r : maps.feat) r = -1;
-    for (auto &r : maps.views) r = -1;
-    if (p.ns_pts > 96 || p.ns_feat > 64 || p.ns_views > 32) {
-        zest_set_error("zest_mlp_fwd(bf16): operand of %d/%d/%d positions exceeds the kernel's tables",
-                       p.ns_pts, p.ns_feat, p.ns_views);
-        return (int)hipErrorInvalidValue;
-    }
-    for (int s = 0; s < p.ns_pts; s++) maps.pts[s] = p.map_pts[s];
-    for (int s = 0; s < p.ns_feat; s++) maps.feat[s] = p.map_feat[s];
-    for (int s = 0; s < p.ns_views; s++) maps.views[s] = p.map_views[s];
     const bool mod = p.desc.use_feat != 0;
     const int key = p.nt_pts * 10 + (mod ? p.nt_feat : 0);
     switch (key) {
-        case 40: return launch_one<1, 4, false, 0>(p, maps, tiles, x, M, out, stream);
-        case 42: return launch_one<1, 4, true, 2>(p, maps, tiles, x, M, out, stream);
-        case 44: return launch_one<1, 4, true, 4>(p, maps, tiles, x, M, out, stream);
-        case 60: return launch_one<1, 6, false, 0>(p, maps, tiles, x, M, out, stream);
-        case 62: return launch_one<1, 6, true, 2>(p, maps, tiles, x, M, out, stream);
-        case 64: return launch_one<1, 6, true, 4>(p, maps, tiles, x, M, out, stream);
+        case 40: return launch_one<1, 4, false, 0>(p, tiles, x, M, out, stream);
+        case 42: return launch_one<1, 4, true, 2>(p, tiles, x, M, out, stream);
+        case 44: return launch_one<1, 4, true, 4>(p, tiles, x, M, out, stream);
+        case 60: return launch_one<1, 6, false, 0>(p, tiles, x, M, out, stream);
+        case 62: return launch_one<1, 6, true, 2>(p, tiles, x, M, out, stream);
+        case 64: return launch_one<1, 6, true, 4>(p, tiles, x, M, out, stream);
     }
     zest_set_error("zest_mlp_fwd(bf16): no kernel for %d point units / %d feature units per row "
                    "block (supported: 1..14 source views)", p.nt_pts, mod ? p.nt_feat : 0);

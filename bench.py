@@ -1,14 +1,19 @@
 #!/usr/bin/env python3
 """Throughput of the ZeST-NeRF rendering hot path on MI355X: rendered rays/s.
 
-    python bench.py [--gpus N --steps K --warmup W] [--workload NAME]
+    python bench.py [--gpus N --steps K --warmup W] [--workload NAME] [--mode bf16|f16|f16x3]
+                    [--scaling weak|strong]
 
 A step is one `renderer.rendering(...)` call (the drop-in boundary) over one batch of
 synthetic rays through the fused HIP renderer, inputs resident in HBM.  Default workload
 (BASELINE.json configs[1]): NSFF Balloon1 geometry, 1024 rays x 128 samples, static MLP,
-bf16 MFMA.  With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank
-renders its own 1024-ray shard and the rendered pixels are all-gathered over RCCL inside the
-timed step (weak scaling: per-GPU work fixed).
+bf16 MFMA.  With N > 1 there is one rank per GPU - started by torch.distributed.run, or by this
+script itself when it is called from a plain shell (it spawns the ranks as child processes
+before touching the GPU) - every rank renders its own ray shard and the rendered pixels are
+all-gathered over RCCL inside the timed region (weak scaling: per-GPU work fixed; --scaling
+strong splits the workload's rays over the GPUs, e.g. configs[3]: 4096 x 192 over 8).
+At N = 1 the JSON also carries `modes`: the fp16 and the fp32-tolerance (split fp16) runs of the
+same kernel on the same workload.
 
 Prints ONE JSON line: metric/value/unit..., plus
   roofline:     MFMA bound for the fused kernel - algorithmic MLP FLOPs per launch / average
@@ -177,39 +182,107 @@ def cpu_baseline(d, budget_s=15.0, build_ret=None):
     return out, psnr
 
 
+MODES = {            # name: (args.precision, args.zest_dtype16, dense MFMA peak the mode is priced against)
+    "bf16": (16, "bf16", PEAK_BF16_TFLOPS),
+    "f16": (16, "f16", PEAK_BF16_TFLOPS),          # fp16 MFMA: the bf16 rate (MI355X_MICROARCH.md, Matrix cores)
+    "f16x3": (32, "bf16", PEAK_BF16_TFLOPS),       # fp32 mode of the fused renderer: 3 fp16 MFMAs per product
+}
+
+
+def set_mode(d, mode):
+    d.args.precision, d.args.zest_dtype16 = MODES[mode][0], MODES[mode][1]
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(a, argv):
+    """`python bench.py --gpus N` from a plain shell: start N ranks (one per GPU) with
+    torch.distributed.run as CHILD processes and hand their exit code on.  This process has made
+    no GPU call (nothing here touches torch.cuda) and never replaces itself with another program."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def _dry_maps(rank, R, step):
+    """Stand-in for the rendered maps of one step in --dry runs (CPU, no HIP): row r of rank g holds
+    its global ray index, so the gathered tensor can be checked."""
+    base = torch.arange(rank * R, (rank + 1) * R, dtype=torch.float32)
+    return base[:, None].repeat(1, 16) + 0.001 * step
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="nsff_static_1024x128", choices=list(WORKLOADS))
-    ap.add_argument("--rays", type=int, default=None, help="rays per GPU (default: the workload's)")
+    ap.add_argument("--mode", default="bf16", choices=list(MODES),
+                    help="operand type of the headline line (BASELINE configs[1]: bf16)")
+    ap.add_argument("--rays", type=int, default=None,
+                    help="rays per GPU (weak scaling) / in total (strong scaling); default: the workload's")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every GPU renders the workload's ray count; strong: the ray count is split over the GPUs")
     ap.add_argument("--gather", default="image", choices=["image", "step"],
                     help="N>1: all-gather the rendered maps once per image (default) or per call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-modes", action="store_true", help="skip the extra f16 / f16x3 lines of the JSON")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--dry", action="store_true",
+                    help="CPU rehearsal of the launcher + collective (gloo, stand-in maps, no HIP): tests only")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(a, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (a.gpus, world))
+    if not a.dry and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the rendering path has no CPU fallback")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    dev = torch.device("cpu")
+    if not a.dry:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     dist = None
     if world > 1 or "RANK" in os.environ:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    if a.gpus != world and rank == 0:
-        print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (a.gpus, world), file=sys.stderr)
+        if a.dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dist.get_world_size() != a.gpus:
+            raise SystemExit("bench.py: process group has %d ranks, --gpus %d" % (dist.get_world_size(), a.gpus))
 
-    import zest_hip
-    zest_hip.lib()
-    d = build_workload(a.workload, 1234 + rank, dev, a.rays)
+    total_rays = a.rays or WORKLOADS[a.workload]["R"]
+    if a.scaling == "strong":
+        if total_rays % world:
+            raise SystemExit("bench.py: %d rays do not split over %d GPUs" % (total_rays, world))
+        rays_per_gpu = total_rays // world
+    else:
+        rays_per_gpu = total_rays
     import zest_parallel
+    if a.dry:
+        d = SimpleNamespace(R=rays_per_gpu, S=WORKLOADS[a.workload]["S"], cfg=WORKLOADS[a.workload])
+    else:
+        import zest_hip
+        zest_hip.lib()
+        d = build_workload(a.workload, 1234 + rank, dev, rays_per_gpu)
+        set_mode(d, a.mode)
     force = os.environ.get("ZEST_FORCE_COLLECTIVE") == "1" and dist is not None     # 1-rank rehearsal
     # Multi-GPU (SURVEY 8(e)): rank g renders its own ray blocks; the packed per-ray maps reach every
     # rank by ONE RCCL all-gather, either per rendering call (--gather step) or, as the reference's
@@ -217,16 +290,22 @@ def main():
     # of IMAGE_PIXELS rays (--gather image, default): every rank keeps its chunks and pushes them
     # in one message, so the latency-bound collective is paid once per image, not per chunk.
     per_image = max(1, IMAGE_PIXELS // max(1, world * d.R))
-    chunks = []
+    chunks, gathered, n_step = [], [], [0]
 
     def flush():
         if chunks:
-            local = chunks[0] if len(chunks) == 1 else torch.cat(chunks, 0)
-            zest_parallel.gather_maps(local, world * local.shape[0], force=force)
+            loc = chunks[0] if len(chunks) == 1 else torch.cat(chunks, 0)
+            full = zest_parallel.gather_maps(loc, world * loc.shape[0], force=force)
+            if a.dry:
+                gathered.append(full)
             chunks.clear()
 
     def step():
-        ret = render_step(d)
+        if a.dry:
+            ret = {"zest_packed_maps": _dry_maps(rank, d.R, n_step[0])}
+            n_step[0] += 1
+        else:
+            ret = render_step(d)
         if world > 1 or force:
             chunks.append(ret["zest_packed_maps"])
             if a.gather == "step" or len(chunks) >= per_image:
@@ -235,55 +314,107 @@ def main():
 
     def fence():
         flush()                     # rays rendered in the timed region are gathered inside it
-        if world > 1 or force:
+        if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not a.dry:
+            torch.cuda.synchronize()
 
-    with torch.no_grad():
-        for _ in range(a.warmup):
-            step()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            step()
-        fence()
-        el = time.perf_counter() - t0
-        # per-launch kernel time from HIP events on the launch stream (outside the timed region)
+    def timed_loop():
+        """W warm-up steps, then K steps between two fences; max over the ranks."""
+        with torch.no_grad():
+            for _ in range(a.warmup):
+                step()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                step()
+            fence()
+            el = time.perf_counter() - t0
+        tmax = torch.tensor([el], device=dev, dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax.item())
+
+    def kernel_ms():
+        """per-launch time of the fused kernel from HIP events on the launch stream"""
         evs = []
-        for _ in range(min(a.steps, 50)):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            render_step(d)
-            e1.record()
-            evs.append((e0, e1))
-        torch.cuda.synchronize()
-        k_ms = float(np.mean([x.elapsed_time(y) for x, y in evs]))
-    tmax = torch.tensor([el], device=dev, dtype=torch.float64)
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    el = float(tmax.item())
+        with torch.no_grad():
+            for _ in range(min(a.steps, 50)):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                render_step(d)
+                e1.record()
+                evs.append((e0, e1))
+            torch.cuda.synchronize()
+        return float(np.mean([x.elapsed_time(y) for x, y in evs]))
+
+    el = timed_loop()
+    if a.dry:
+        # every gathered tensor: `world` equal blocks in rank order, each a run of whole chunks whose
+        # rows carry the global ray indices rank * R .. rank * R + R - 1 in order
+        ok = True
+        for g in gathered:
+            idx = torch.floor(g[:, 0]).long().view(world, -1, d.R)
+            want = (torch.arange(world) * d.R)[:, None, None] + torch.arange(d.R)[None, None, :]
+            ok = ok and bool((idx == want).all())
+        if rank == 0:
+            print(json.dumps({"dry": True, "n_gpus": world, "world_size": dist.get_world_size() if dist else 1,
+                              "steps": a.steps, "warmup": a.warmup, "scaling": a.scaling, "rays_per_gpu": d.R,
+                              "gathers": len(gathered), "gathered_rows": [int(g.shape[0]) for g in gathered[:4]],
+                              "rows_in_order": bool(ok), "value": None}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    k_ms = kernel_ms()
     if rank == 0:
         flops, fps = flops_per_ray_batch(d)
+        peak = MODES[a.mode][2]
         ach = flops / (k_ms * 1e-3) / 1e12
+        coll = "none"
+        if world > 1:
+            coll = ("all_gather(packed per-ray maps) per rendering call" if a.gather == "step" else
+                    "all_gather(packed per-ray maps) once per %d-ray image = every %d calls" % (IMAGE_PIXELS, per_image))
         out = {
-            "metric": "rendered rays/sec (1024-ray x 128-sample batch)", "value": world * d.R * a.steps / el,
+            "metric": "rendered rays/sec (%d-ray x %d-sample batch per GPU)" % (d.R, d.S),
+            "value": world * d.R * a.steps / el,
             "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": a.scaling,
+            "vs_baseline": None, "dtype": a.mode, "data": "synthetic",
             "config": {"workload": a.workload, "rays_per_gpu": d.R, "samples_per_ray": d.S,
-                       "note": d.cfg["note"], "path": "renderer.rendering -> zest_render_fused_fwd",
-                       "collective": ("none" if world == 1 else "all_gather(packed per-ray maps) per rendering call"
-                                      if a.gather == "step" else
-                                      "all_gather(packed per-ray maps) once per %d-ray image = every %d calls"
-                                      % (IMAGE_PIXELS, per_image))},
-            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(a.workload),
-                         "kernel": "fused_blocks_kernel (rays finished in-kernel when 8 blocks hold whole rays; else + fused_combine_kernel)",
+                       "rays_total": world * d.R, "note": d.cfg["note"],
+                       "path": "renderer.rendering -> zest_render_fused_fwd", "collective": coll,
+                       "ranks": dist.get_world_size() if dist is not None else 1,
+                       "backend": ("rccl" if dist is not None else "none")},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                         "frac": ach / peak, "traffic": pmc_traffic(a.workload),
+                         "kernel": "fused_blocks_kernel (rays finished in-kernel when a pass holds whole rays; else + fused_combine_kernel)",
                          "kernel_ms": k_ms, "flop_per_sample": fps,
                          "note": "achieved = algorithmic MLP FLOPs of one launch / HIP-event time of the "
-                                 "launch pair on its stream; traffic = HBM bytes per launch from the "
+                                 "launch on its stream; traffic = HBM bytes per launch from the "
                                  "rocprofv3 PMC passes archived in profiles/ (null if none for this workload)"},
         }
+    if world == 1 and not a.no_modes:
+        # the other operand types of the same kernel on the same workload: fp16 (configs[4]) and the
+        # fp32-tolerance mode (split fp16, north-star 1e-4 abs / 1e-3 rel), same protocol
+        modes = {}
+        for m in MODES:
+            if m == a.mode:
+                continue
+            set_mode(d, m)
+            el_m = timed_loop()
+            km = kernel_ms()
+            fl, _ = flops_per_ray_batch(d)
+            ach_m = fl / (km * 1e-3) / 1e12
+            modes[m] = {"value": d.R * a.steps / el_m, "unit": "rays/s", "ms_per_step": el_m / a.steps * 1e3,
+                        "kernel_ms": km, "roofline": {"bound": "mfma", "achieved": ach_m, "peak": MODES[m][2],
+                                                      "unit": "TFLOP/s", "frac": ach_m / MODES[m][2]}}
+        modes["f16x3"]["note"] = ("fp32 mode of the fused renderer: every product is 3 fp16 MFMAs (hi*hi + hi*lo + lo*hi); "
+                                  "achieved counts the ALGORITHMIC FLOPs once, so frac <= 1/3 by construction; "
+                                  "executed MFMA work = 3x; against the fp32 MFMA peak (157.3 TFLOP/s) the same "
+                                  "number is %.2fx" % (modes["f16x3"]["roofline"]["achieved"] / 157.3)) if "f16x3" in modes else None
+        set_mode(d, a.mode)
+        out["modes"] = modes
+    if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             with torch.no_grad():
                 build_ret = render_step(d)

@@ -24,11 +24,17 @@
 extern "C" {
 #endif
 
-#define ZEST_ABI_VERSION 1
+#define ZEST_ABI_VERSION 2
 
 /* arithmetic of the MLP contraction */
 #define ZEST_PREC_F32  0   /* v_mfma_f32_32x32x2_f32: exact fp32 products, parity mode */
 #define ZEST_PREC_BF16 1   /* v_mfma_f32_16x16x32_bf16: bf16 operands, fp32 accumulate  */
+#define ZEST_PREC_F16  2   /* v_mfma_f32_16x16x32_f16: fp16 operands (11-bit significand), */
+                           /* fp32 accumulate; activations beyond 65504 saturate          */
+#define ZEST_PREC_F16X3 3  /* fp32-class results on the fp16 matrix pipe: every operand is */
+                           /* the pair (hi, lo) = (fp16(v), fp16((v - hi) * 2^11)) and a  */
+                           /* product is hi*hi + 2^-11 (hi*lo + lo*hi): 22 significant    */
+                           /* bits per operand, 3 MFMAs per product, fp32 accumulate       */
 
 /* extra heads of the MLP (reference networks.py:115-123) */
 #define ZEST_HEAD_NONE    0  /* out = rgb(3) sigma(1)                                     */
@@ -254,9 +260,13 @@ int zest_mlp_fwd(const zest_mlp_desc *desc, int precision, const void *packed,
 /* ---- fused inference path ---------------------------------------------------------
  * rendering(..., val=True) (reference renderer.py:579-626 with the early return at
  * :444-445): encode + feature gathers + static MLP [+ dynamic MLP] + per-block compositing
- * in one launch, nothing per-sample written to HBM.  The 32-sample blocks of a ray are chained
- * inside that launch when 8 blocks hold whole rays (S <= 32, 64, 128, 256), otherwise by a
- * second tiny launch reading the block records from `workspace`.
+ * in one launch, nothing per-sample written to HBM.  precision: ZEST_PREC_BF16, _F16 or _F16X3
+ * (the packed weights must have been packed for it); _F16X3 is the fp32 mode of this path
+ * (results within 1e-4 abs / 1e-3 rel of the fp32 reference).  A ray is cut into blocks of 32
+ * samples (16 for _F16X3), one per wave of an 8-wave workgroup pass.  The blocks of a ray are
+ * chained inside the launch when a pass holds whole rays (ray-aligned passes: up to 8 blocks
+ * per ray, taken whenever that costs no extra round of passes on the device); otherwise
+ * (dense passes) by a second tiny launch reading the block records from `workspace`.
  * out [R,16]: 0-2 rgb_map, 3 depth_map, 4 acc_map; with the dynamic net also
  * 5-7 rgb_map_ref, 8 depth_map_ref, 9-11 rgb_map_ref_dy, 12 depth_map_ref_dy,
  * 13 weights_map_dd; 14,15 reserved. */
@@ -270,8 +280,13 @@ typedef struct zest_view_set {
 } zest_view_set;
 
 /* bytes of caller-owned scratch zest_render_fused_fwd needs for R rays of S samples
- * (one 80-byte record per 32-sample block) */
+ * (one 80-byte record per block of 16 samples, the smallest block of any precision) */
 size_t zest_render_fused_workspace(int R, int S);
+
+/* Pass shape of zest_render_fused_fwd for the whole process: 0 = chosen per launch (default),
+ * 1 = dense passes + combine launch, 2 = ray-aligned passes wherever a ray fits one pass.
+ * Results are identical; a knob for tests and measurements. */
+int zest_render_fused_set_passes(int shape);
 
 int zest_render_fused_fwd(const float *ndc, const float *pts, const float *z,
                           const float *rays_dir, int R, int S,

@@ -2,7 +2,7 @@
 #include <cstdio>
 int main() {
     int n = 0;
-    for (int prec = 0; prec < 2; prec++)
+    for (int prec = 0; prec < 4; prec++)
         for (int order = 0; order < 2; order++)
             for (int pts : {63, 84})
                 for (int use_feat = 0; use_feat < 2; use_feat++)
@@ -14,8 +14,21 @@ int main() {
                                 d.use_feat = use_feat, d.net_type = nt, d.head = head;
                                 zest::MlpPlan p;
                                 const char *err = nullptr;
-                                const int precision = prec == 0 ? ZEST_PREC_F32 : ZEST_PREC_BF16;
-                                if (zest::build_plan(d, precision, order, &p, &err, true)) n++;
+                                const int precision = prec;      // ZEST_PREC_F32, _BF16, _F16, _F16X3
+                                if (!zest::build_plan(d, precision, order, &p, &err, true)) continue;
+                                n++;
+                                // a split plan doubles every tile unit and nothing else
+                                if (precision == ZEST_PREC_F16X3) {
+                                    zest::MlpPlan q;
+                                    if (!zest::build_plan(d, ZEST_PREC_F16, order, &q, &err, false)) return 2;
+                                    int hdr = 0, lo = 0;
+                                    for (int o = 0; o < zest::kNumOps; o++) hdr += p.op[o].njb;
+                                    for (size_t u = 0; u < p.unit_part.size(); u++) lo += p.unit_part[u];
+                                    int raw_q = 0, raw_p = 0;
+                                    for (int o = 0; o < zest::kNumOps; o++)
+                                        raw_q += q.op[o].njb * q.op[o].tiles_per_jb, raw_p += p.op[o].njb * p.op[o].tiles_per_jb;
+                                    if (raw_p - hdr != 2 * (raw_q - hdr) || lo != raw_q - hdr || p.parts != 2) return 3;
+                                }
                             }
     std::printf("plans built: %d\n", n);
     return n > 0 ? 0 : 1;

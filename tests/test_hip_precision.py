@@ -1,0 +1,194 @@
+"""GPU: the operand types of the MFMA engine (include/zest_render.h ZEST_PREC_*).
+
+  f16x3  split-fp16 pairs, the fp32 mode of the fused renderer: held to BASELINE.json's fp32
+         tolerance, 1e-4 abs + 1e-3 rel PER ELEMENT, against the reference fixtures and the oracle
+  f16    fp16 operands (BASELINE configs[4]): 11 significant bits through 10 layers
+  bf16   8 significant bits (configs[1])
+and every instantiation of the fused kernel (static feature tiles 0 / 2 / 4 x dynamic net none /
+plain / with features) in each of them, the 'v2' net, and both pass shapes (ray-aligned passes
+that finish rays in the kernel; dense passes + the combine launch).
+"""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+import oracle_run as orun
+from test_hip_ops import G, close, ATOL, RTOL, MLP_CASES, _mlp_setup
+from test_hip_render import call_rendering, render_scene
+
+pytestmark = pytest.mark.gpu
+
+MAP_KEYS = ("rgb_map", "depth_map", "rgb_map_ref", "depth_map_ref", "rgb_map_ref_dy", "depth_map_ref_dy",
+            "weights_map_dd")
+# per-ray map tolerances of the 16-bit modes (absolute; colours / depths): measured worst cases on the
+# fixtures are 7e-3 / 3e-2 (bf16) and 6e-4 / 3e-3 (f16)
+TOL16 = {"bf16": (2e-2, 6e-2), "f16": (3e-3, 1e-2)}
+
+
+def close_rays(got, want, atol, rtol, name, max_bad=0):
+    """close() per ray, tolerating `max_bad` rays.  The reference gives the LAST sample of a ray a 1e10
+    interval (renderer.py:84): alpha there is 1 for any sigma > 0 and 0 otherwise, so a ray whose last
+    density is ~0 flips between 'saturated' and 'empty' under 16-bit operand noise - a discontinuity
+    of the reference's formula, not of the kernel."""
+    g, w = got.double().cpu().numpy(), np.asarray(want, np.float64)
+    bad = (np.abs(g - w) > atol + rtol * np.abs(w)).reshape(g.shape[0], -1).any(-1)
+    assert bad.sum() <= max_bad, "%s: %d rays outside %g + %g |ref| (max abs %.3g)" % (
+        name, bad.sum(), atol, rtol, np.abs(g - w).max())
+
+
+# ------------------------------------------------------------------------- standalone MLP
+@pytest.mark.parametrize("case", MLP_CASES)
+def test_mlp_split_fp16_meets_fp32_tolerance(hip, case):
+    zh, inp, desc, tab = _mlp_setup(case)
+    y = zh.mlp_fwd(desc, zh.PREC_F16X3, zh.mlp_pack(desc, zh.PREC_F16X3, tab), G(inp["x"])[0])
+    close(y, gc.load_golden(case)["y"], atol=ATOL, rtol=RTOL, name=case)
+
+
+@pytest.mark.parametrize("case", MLP_CASES)
+def test_mlp_fp16(hip, case):
+    zh, inp, desc, tab = _mlp_setup(case)
+    y = zh.mlp_fwd(desc, zh.PREC_F16, zh.mlp_pack(desc, zh.PREC_F16, tab), G(inp["x"])[0])
+    gold = gc.load_golden(case)["y"]
+    close(y, gold, atol=4e-3 * np.abs(gold).max(), rtol=4e-3, name=case)
+
+
+def test_mlp_split_fp16_ragged_and_tiny_values(hip):
+    """M not a multiple of the 16-row tile; inputs and weights scaled down so that hi parts are fp16
+    subnormals (|v| < 6.1e-5): the scaled lo part keeps the product exact to fp32 level."""
+    zh, inp, desc, tab = _mlp_setup("mlp_static_mvs20")
+    gold = gc.load_golden("mlp_static_mvs20")["y"]
+    packed = zh.mlp_pack(desc, zh.PREC_F16X3, tab)
+    for M in (1, 15, 17, 45):
+        close(zh.mlp_fwd(desc, zh.PREC_F16X3, packed, G(inp["x"])[0, :M]), gold[:M], name="M=%d" % M)
+    import zest_synth as zs
+    from oracle import zest_oracle as zo
+    lay = zs.mlp_layout(gc.PE_PTS, gc.PE_DIR, 20, False, True, True)
+    state = zs.fill_mlp_state(lay, 4242)
+    state["nerf.pts_linears.0.weight"] = state["nerf.pts_linears.0.weight"] * 1e-3      # first layer ~1e-5 .. 1e-4
+    x = zs.rng(4243).uniform(-1, 1, size=(70, gc.PE_PTS + 20 + gc.PE_DIR)).astype(np.float32)
+    x[:, :gc.PE_PTS] *= 3e-2
+    with torch.no_grad():
+        want = zo.mlp_forward(orun.state_t(state, torch.float64), torch.from_numpy(x).double(),
+                              orun.spec_of(gc.PE_PTS, 20, False, True, True)).numpy()
+    d2 = zh.MlpDesc(gc.PE_PTS, 20, gc.PE_DIR, 1, 0, zh.HEAD_NONE)
+    t2 = zh.param_table({k: G(v) for k, v in state.items()}, d2)
+    close(zh.mlp_fwd(d2, zh.PREC_F16X3, zh.mlp_pack(d2, zh.PREC_F16X3, t2), G(x)), want, name="tiny operands")
+
+
+# ------------------------------------------------------------------- fused renderer, fixtures
+FUSED_CASES = ["render_static_mvs", "render_static_nomvs", "render_static_white", "render_zest_val",
+               "render_zest_nomvsdy"]
+
+
+@pytest.mark.parametrize("case", FUSED_CASES)
+def test_fused_fp32_mode_meets_north_star_tolerance(hip, case):
+    """args.precision = 32 + the fused plan: ONE launch on split-fp16 pairs.  Every per-ray map within
+    1e-4 abs + 1e-3 rel of the reference's golden outputs, element by element, and of the exact-product
+    fp32 per-op path."""
+    fused = call_rendering(case, 32, maps_only=True)
+    perop = call_rendering(case, 32)
+    gold = gc.load_golden(case)
+    keys = [k for k in MAP_KEYS if k in gold]
+    assert set(k for k in fused if k not in ("acc_map", "zest_packed_maps")) == set(keys)
+    for k in keys:
+        close(fused[k][0], gold[k], atol=ATOL, rtol=RTOL, name="x3~ref/%s/%s" % (case, k))
+        close(fused[k][0], perop[k][0].cpu().numpy(), atol=ATOL, rtol=RTOL, name="x3~fp32 per-op/%s/%s" % (case, k))
+
+
+@pytest.mark.parametrize("case", FUSED_CASES)
+def test_fused_fp16_mode(hip, case):
+    fused = call_rendering(case, 16, maps_only=True, dtype16="f16")
+    perop = call_rendering(case, 16, dtype16="f16")
+    gold = gc.load_golden(case)
+    for k in [k for k in MAP_KEYS if k in gold]:
+        tol = TOL16["f16"][1 if "depth" in k else 0]
+        close_rays(fused[k][0], gold[k], tol, 0, "f16~ref/%s/%s" % (case, k), max_bad=1)
+        close_rays(fused[k][0], perop[k][0].cpu().numpy(), tol, 0, "f16 fused~per-op/%s/%s" % (case, k), max_bad=1)
+
+
+# ------------------------------------------------------- every kernel instantiation x operand type
+def _variant_scene(tag):
+    """Scene that dispatches to fused variant `tag` (csrc/fused.hip ZEST_CASE keys)."""
+    V = {"s0": None, "s2": 3, "s4": 8}[tag[:2]]
+    dyn = {"": None, "d0": False, "d2": True}[tag[2:]]
+    seed = 1500 + sum(map(ord, tag))
+    sc = gc.render_inputs(seed, R=40, S=40, V=V or 3, use_mvs=V is not None, scene_flow=dyn is not None,
+                          use_mvs_dy=bool(dyn))
+    return sc
+
+
+VARIANTS = ["s0", "s2", "s4", "s0d0", "s2d0", "s4d0", "s2d2", "s4d2"]
+
+
+@pytest.mark.parametrize("mode", ["f16x3", "f16", "bf16"])
+@pytest.mark.parametrize("tag", VARIANTS)
+def test_every_fused_variant_against_the_oracle(hip, tag, mode):
+    sc = _variant_scene(tag)
+    c = dict(val=True)
+    want = orun.oracle_render(c, sc)
+    kw = dict(precision=32) if mode == "f16x3" else dict(precision=16, dtype16=mode)
+    got = render_scene(sc, c, maps_only=True, **kw)
+    keys = [k for k in MAP_KEYS if k in got]
+    assert len(keys) == (7 if sc["scene_flow"] else 2)
+    for k in keys:
+        w = want[k].numpy()
+        if mode == "f16x3":
+            close(got[k][0], w, atol=ATOL, rtol=RTOL, name="%s/%s/%s" % (tag, mode, k))
+        else:
+            close_rays(got[k][0], w, TOL16[mode][1 if "depth" in k else 0], 0, "%s/%s/%s" % (tag, mode, k), max_bad=1)
+
+
+@pytest.mark.parametrize("mode", ["f16x3", "f16", "bf16"])
+def test_fused_v2_net(hip, mode):
+    """'v2' nets (Renderer_linear: additive modulation, activations inside the net AND again in the
+    compositor, reference networks.py:294-314 + renderer.py:134,141) through the fused kernel."""
+    import zest_synth as zs
+    from oracle import zest_oracle as zo
+    sc = gc.render_inputs(1777, R=24, S=48, V=3, use_mvs=True)
+    lay = zs.mlp_layout(gc.PE_PTS, gc.PE_DIR, sc["feat_dim"], False, True, True)
+    sc["state_static"] = zs.fill_mlp_state(lay, 1778)
+    t = lambda k: orun.T(sc[k])[0]
+    ns = zo.Net(orun.state_t(sc["state_static"]), orun.spec_of(gc.PE_PTS, sc["feat_dim"], False, True, True, "v2"))
+    with torch.no_grad():
+        want = zo.rendering(t("rays_pts"), t("rays_ndc"), t("depth_candidates"), t("rays_dir"), ns, None,
+                            vol_static=t("vol_static"), imgs=t("imgs"), cams=(t("w2cs"), t("intrinsics")),
+                            scene_flow=False, val=True, explicit=True)
+    kw = dict(precision=32) if mode == "f16x3" else dict(precision=16, dtype16=mode)
+    got = render_scene(sc, dict(val=True), maps_only=True, net_type="v2", **kw)
+    perop = render_scene(sc, dict(val=True), precision=32, net_type="v2")
+    for k in ("rgb_map", "depth_map"):
+        w = want[k].numpy()
+        close(perop[k][0], w, name="v2 fp32 per-op/" + k)
+        if mode == "f16x3":
+            close(got[k][0], w, atol=ATOL, rtol=RTOL, name="v2/%s/%s" % (mode, k))
+        else:       # additive modulation: activations (and their 16-bit rounding errors) ~2x those of a 'v0' net
+            close_rays(got[k][0], w, 2.5 * TOL16[mode][1 if "depth" in k else 0], 0, "v2/%s/%s" % (mode, k), max_bad=1)
+
+
+# ------------------------------------------------------------------------------ pass shapes
+@pytest.mark.parametrize("mode", ["f16x3", "bf16"])
+@pytest.mark.parametrize("R,S", [(40, 96), (40, 192), (8, 250), (9, 300), (300, 192)])
+def test_pass_shapes_agree(hip, R, S, mode, monkeypatch):
+    """bpr = 3, 6, 8 (aligned passes with idle waves), > 8 waves per ray (dense only) and a batch
+    large enough that the dispatcher picks dense passes by itself: the in-kernel ray finishing and
+    the HBM-record + combine launch give the same maps bit for bit, with both nets (a dynamic
+    case reaches fused_combine_kernel's blended records), and match the oracle in fp32 mode."""
+    import zest_hip
+    sc = gc.render_inputs(2100 + R + S, R=R, S=S, V=3, use_mvs=True, scene_flow=True, use_mvs_dy=True)
+    c = dict(val=True)
+    kw = dict(precision=32) if mode == "f16x3" else dict(precision=16, dtype16=mode)
+    outs = {}
+    for shape in ("dense", "aligned", None):
+        # the library reads ZEST_FUSED_PASSES once per process: use its setter instead of the environment
+        zest_hip.set_fused_passes(shape)
+        outs[shape] = render_scene(sc, c, maps_only=True, **kw)["zest_packed_maps"].clone()
+    zest_hip.set_fused_passes(None)
+    assert torch.equal(outs["dense"], outs["aligned"]) and torch.equal(outs["dense"], outs[None])
+    if mode == "f16x3":
+        want = orun.oracle_render(c, sc)
+        got = render_scene(sc, c, maps_only=True, **kw)
+        for k in MAP_KEYS:
+            close(got[k][0], want[k].numpy(), atol=ATOL, rtol=RTOL, name="%dx%d/%s" % (R, S, k))

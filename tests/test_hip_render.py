@@ -20,11 +20,11 @@ RENDER_CASES = [c for c in gc.CASES if gc.CASES[c]["kind"] == "render"]
 CHAIN2 = ("raw_pts_pp", "rgb_map_pp_dy")
 
 
-def build_nets(sc):
+def build_nets(sc, net_type="v0"):
     import networks
     sf = sc["scene_flow"]
     ns = networks.MVSNeRF(D=8, W=256, input_ch_pts=gc.PE_PTS, output_ch=4, input_ch_views=gc.PE_DIR,
-                          input_ch_feat=sc["feat_dim"], skips=[4], net_type="v0", sceneflow=sf,
+                          input_ch_feat=sc["feat_dim"], skips=[4], net_type=net_type, sceneflow=sf,
                           static=True, use_mvs=sc["use_mvs"])
     ns.load_state_dict({k: torch.from_numpy(v) for k, v in sc["state_static"].items()})
     nd = None
@@ -37,15 +37,15 @@ def build_nets(sc):
     return ns.to("cuda:0"), nd
 
 
-def call_rendering(case, precision=32, monkeypatch=None, maps_only=False):
+def render_scene(sc, c, precision=32, monkeypatch=None, maps_only=False, dtype16="bf16", net_type="v0"):
+    """renderer.rendering on a scene dict of golden_cases.render_inputs with the flags of case dict c."""
     import networks
     import renderer
-    c, sc = gc.CASES[case], gc.build(case)
     sf = sc["scene_flow"]
-    ns, nd = build_nets(sc)
+    ns, nd = build_nets(sc, net_type)
     args = SimpleNamespace(netchunk=1024, feat_dim=sc["feat_dim"], feat_dim_dy=24, img_downscale=1.0,
-                           use_color_volume=False, net_type="v0", precision=precision,
-                           zest_maps_only=maps_only)
+                           use_color_volume=False, net_type=net_type, precision=precision,
+                           zest_maps_only=maps_only, zest_dtype16=dtype16)
     cam = {"w2cs": G(sc["w2cs"]), "intrinsics": G(sc["intrinsics"])}
     dy = sf and sc["use_mvs_dy"]
     nb_cam = {"w2cs": G(sc["nb_w2cs"]), "intrinsics": G(sc["nb_intrinsics"])} if dy else None
@@ -66,6 +66,10 @@ def call_rendering(case, precision=32, monkeypatch=None, maps_only=False):
             ref_frame_idx=gc.REF_FRAME_IDX, num_frames=gc.NUM_FRAMES,
             white_bkgd=c.get("white_bkgd", False), scene_flow=sf, val=c.get("val", False),
             raw_noise_std=c.get("raw_noise_std", 0))
+
+
+def call_rendering(case, precision=32, monkeypatch=None, maps_only=False, dtype16="bf16"):
+    return render_scene(gc.build(case), gc.CASES[case], precision, monkeypatch, maps_only, dtype16)
 
 
 @pytest.mark.parametrize("case", RENDER_CASES)

@@ -12,9 +12,17 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libzest_hip.so")
-SOURCES = ["capi.hip", "composite.hip", "composite_bwd.hip", "encode.hip", "rays.hip", "volume_cost.hip", "losses.hip", "mlp_plan.hip", "mlp.hip", "mlp_bf16.hip", "mlp_train.hip",
-           "fused.hip", "fused_s0.hip", "fused_s2.hip", "fused_s4.hip", "fused_s0d0.hip",
-           "fused_s4d2.hip", "fused_s2d2.hip", "fused_s2d0.hip", "fused_s4d0.hip"]
+SOURCES = ["capi.hip", "composite.hip", "composite_bwd.hip", "encode.hip", "rays.hip", "volume_cost.hip", "losses.hip", "mlp_plan.hip", "mlp.hip", "mlp_engine.hip", "mlp_train.hip",
+           "fused.hip"]
+# fused renderer instantiations: fused_variant.hip once per (operand type, feature shape);
+# heaviest first so the pool drains evenly
+_SHAPES = [("s4d2", 4, "true", 2), ("s2d2", 2, "true", 2), ("s4d0", 4, "true", 0), ("s2d0", 2, "true", 0),
+           ("s0d0", 0, "true", 0), ("s4", 4, "false", 0), ("s2", 2, "false", 0), ("s0", 0, "false", 0)]
+_PRECS = [("x3", "ZEST_PREC_F16X3"), ("bf16", "ZEST_PREC_BF16"), ("f16", "ZEST_PREC_F16")]
+VARIANTS = [("fused_%s_%s" % (pt, tag),
+             ["-DZEST_V_PTAG=%s" % pt, "-DZEST_V_EP=%s" % ep, "-DZEST_V_TAG=%s" % tag, "-DZEST_V_NTS=%d" % nts,
+              "-DZEST_V_DYN=%s" % dyn, "-DZEST_V_NTD=%d" % ntd])
+            for tag, nts, dyn, ntd in _SHAPES for pt, ep in _PRECS]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-Wno-inline-asm",     # the LDS-DMA asm declares the reserved register m0 clobbered on purpose
@@ -35,16 +43,22 @@ def _stale(target, srcs):
     return any(os.path.getmtime(s) > t for s in srcs if os.path.exists(s))
 
 
-def _compile(src, extra):
-    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+def _compile(src, extra, objname=None):
+    obj = os.path.join(OBJ, (objname or src.replace(".hip", "")) + ".o")
     path = os.path.join(CSRC, src)
     if _stale(obj, [path] + _deps()):
-        cmd = [HIPCC] + FLAGS + extra + ["-c", path, "-o", obj]
+        cmd = [HIPCC] + FLAGS + extra + ["-Rpass-analysis=kernel-resource-usage", "-c", path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-6000:]))
-        if r.stderr.strip():
-            sys.stderr.write(r.stderr)
+        # register / scratch / LDS use of every kernel: kept next to the object (tools/kernel_resources.py)
+        remarks = [l for l in r.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" in l]
+        with open(obj[:-2] + ".remarks", "w") as f:
+            f.write("\n".join(remarks) + "\n")
+        rest = [l for l in r.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in l
+                and "loop not unrolled" not in l]
+        if any(("warning" in l or "error" in l) for l in rest):
+            sys.stderr.write("\n".join(rest) + "\n")
     return obj
 
 
@@ -56,14 +70,18 @@ def build(force=False, extra_flags=(), tag=None, only=None):
         OBJ = os.path.join(CSRC, "build_" + tag)
         LIB = os.path.join(HERE, "libzest_hip_%s.so" % tag)
     os.makedirs(OBJ, exist_ok=True)
-    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s)) and (not only or s in only)]
+    every = [(name, "fused_variant.hip", flags) for name, flags in VARIANTS]
+    every += [(s.replace(".hip", ""), s, []) for s in SOURCES]
+    jobs = [j for j in every if not only or j[0] in only or j[1] in only]
     if force:
-        for s in srcs:
-            o = os.path.join(OBJ, s.replace(".hip", ".o"))
+        for name, _, _ in jobs:
+            o = os.path.join(OBJ, name + ".o")
             if os.path.exists(o):
                 os.remove(o)
-    with ThreadPoolExecutor(max_workers=min(7, len(srcs))) as ex:
-        objs = list(ex.map(lambda s: _compile(s, list(extra_flags)), srcs))
+    with ThreadPoolExecutor(max_workers=int(os.environ.get("ZEST_BUILD_JOBS", "8"))) as ex:
+        objs = list(ex.map(lambda j: _compile(j[1], j[2] + list(extra_flags), j[0]), jobs))
+    default_obj = os.path.join(CSRC, "build")
+    objs += [os.path.join(default_obj, j[0] + ".o") for j in every if j not in jobs]
     if _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lrocblas"]
         r = subprocess.run(cmd, capture_output=True, text=True)

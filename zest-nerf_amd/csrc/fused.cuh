@@ -40,11 +40,11 @@ struct FusedArgs {
     FusedNet st, dy;
     float frame_idx;
     int white_bkgd;
-    int bpr;                              // 32-sample blocks per ray = ceil(S / 32)
+    int bpr;                              // blocks per ray = ceil(S / block samples)
     float *partials;                      // [R*bpr, kPartialFloats] workspace
     float *out;                           // [R,16]
     unsigned long long *stamps;           // diagnostic builds (ZEST_STAMPS): 8 u64 per wave, else null
-    int combine_in_kernel;                // bpr divides the blocks of a pass: rays are finished in the pass
+    int rays_per_pass;                    // > 0: a pass holds this many whole rays and finishes them itself
 };
 
 // Chains the per-block records of one ray (exit transmittance + weighted sums, entry
@@ -75,26 +75,21 @@ __device__ __forceinline__ void combine_ray(Rec rec, int bpr, bool dyn, int whit
     o[3] = make_float4(fg[3], bl[4], 0.f, 0.f);
 }
 
-__device__ __forceinline__ bf16x8 pack_tile(const float (&v)[8]) {
-    uint4 a = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]),
-                         pack_bf16(v[6], v[7]));
-    return *reinterpret_cast<bf16x8 *>(&a);
-}
-
 // Positional-encoding operand for C coordinates and L (even) bands in plan position order
 // (mlp_plan.hip pe_map_acc): element e of k-tile kt is m = 8 kt + e; m < (L/2) C is
 // sin (g even) / cos (g odd) of 2^(2 (m / C) + (g >> 1)) x[m % C]; m = (L/2) C is the raw
 // coordinate x[g]; zero after that.
-// The engine rounds operands to bf16 (8 significant bits), so the hardware sine is used:
-// v_sin_f32 takes revolutions, cos is sin shifted by a quarter revolution, and the range
-// reduction is one v_fract.  Its absolute error (~1e-6) plus the rounding of arg/(2 pi)
-// (3e-5 rad at 2^9 x) is 1/50 of a bf16 ulp; the fp32 per-op path (encode.hip) keeps the
-// accurate sincos.
-template <int C, int L, int NK>
-__device__ __forceinline__ void encode_pe_operand(const float (&x)[4], int grp, OpArr<NK> &op) {
+// bf16 / fp16 operands (8 / 11 significant bits): the hardware sine is used: v_sin_f32 takes
+// revolutions, cos is sin shifted by a quarter revolution, and the range reduction is one
+// v_fract.  Its absolute error (~1e-6) plus the rounding of arg/(2 pi) (3e-5 rad at 2^9 x) is
+// 1/50 of a bf16 ulp and 1/6 of an fp16 ulp.  The split-fp16 mode (fp32-class results) takes
+// the accurate Cody-Waite sincos of the fp32 per-op path (zest_common.cuh, 9e-8 abs).
+template <int EP, int C, int L, int NK>
+__device__ __forceinline__ void encode_pe_operand(const float (&x)[4], int grp, OpArr<NK, ep_parts(EP)> &op) {
     static_assert((L / 2) * C + 1 <= NK * 8 && L % 2 == 0, "position layout");
     const float quarter = (grp & 1) ? 0.25f : 0.0f;
     const float gscale = (grp & 2) ? 2.0f * 0.15915494309189535f : 0.15915494309189535f;
+    const float gband = (grp & 2) ? 2.0f : 1.0f;
     float rev[C];
 #pragma unroll
     for (int c = 0; c < C; c++) rev[c] = x[c] * gscale;      // revolutions at the group's band of pair 0
@@ -106,25 +101,31 @@ __device__ __forceinline__ void encode_pe_operand(const float (&x)[4], int grp, 
         for (int e = 0; e < 8; e++) {
             const int m = 8 * t + e;
             if (m < (L / 2) * C) {
-                const float r = fmaf(rev[m % C], (float)(1 << (2 * (m / C))), quarter);
-                v[e] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(r));
+                if constexpr (EP == ZEST_PREC_F16X3) {
+                    float sn, cs;           // the argument 2^band x is exact, as in the reference
+                    zest_sincos(x[m % C] * (gband * (float)(1 << (2 * (m / C)))), &sn, &cs);
+                    v[e] = (grp & 1) ? cs : sn;
+                } else {
+                    const float r = fmaf(rev[m % C], (float)(1 << (2 * (m / C))), quarter);
+                    v[e] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(r));
+                }
             } else if (m == (L / 2) * C) {
                 v[e] = raw;
             } else {
                 v[e] = 0.0f;
             }
         }
-        op.t[t] = pack_tile(v);
+        store_tile<EP>(v, op, t);
     }
 }
 
 // Feature operand (mlp_plan.hip feat_map_acc): a lane's eight values of k-tile kt are the
 // 4-channel quads q = 8 kt + 2 g and q + 1; quad 0 / 2 = volume channels 0-3 / 4-7, quad 1 / 3 =
 // source view 0 / 1, quad q >= 4 = source view q - 2.
-template <int NK>
+template <int EP, int NK>
 __device__ __forceinline__ void encode_feat_operand(const FusedNet &n, const float *cams_lds,
                                                     const float (&ndc)[4], const float (&pw)[3],
-                                                    int grp, bool valid, OpArr<NK> &op) {
+                                                    int grp, bool valid, OpArr<NK, ep_parts(EP)> &op) {
     float v[NK * 8];
 #pragma unroll
     for (int i = 0; i < NK * 8; i++) v[i] = 0.0f;
@@ -191,7 +192,7 @@ __device__ __forceinline__ void encode_feat_operand(const FusedNet &n, const flo
         float w8[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) w8[e] = v[8 * t + e];
-        op.t[t] = pack_tile(w8);
+        store_tile<EP>(w8, op, t);
     }
 }
 
@@ -209,47 +210,75 @@ __device__ __forceinline__ void stage_cams(const FusedNet &n, float *lds) {
 
 #ifndef ZEST_FUSED_WAVES
 #define ZEST_FUSED_WAVES 8         // waves per workgroup (8 = two per SIMD, 256 VGPRs each)
-#define ZEST_FUSED_NB 1            // 32-sample column blocks per wave (tile reads feed NB MFMAs)
 #endif
-constexpr int kFusedWaves = ZEST_FUSED_WAVES, kFusedNB = ZEST_FUSED_NB;
-constexpr int kPartialFloats = 20; // per-block record, see combine_kernel
+constexpr int kFusedWaves = ZEST_FUSED_WAVES;
+constexpr int kPartialFloats = 20; // per-block record, see combine_ray
+// column blocks of 16 samples a wave carries through the network: two, or one where every operand
+// is a register pair (split fp16).  A block of a ray = 16 * CB consecutive samples.
+constexpr int fused_cb(int EP) { return EP == ZEST_PREC_F16X3 ? 1 : 2; }
 
 struct BlockSamples {              // what a lane keeps about its sample across the two nets
     float x[4], pw[3], zz, dist;
     bool valid;
 };
 
-// Work unit: a block of 32 consecutive samples of one ray (rays are padded to bpr blocks).  A
-// pass of the workgroup covers kFusedWaves * kFusedNB blocks; every wave runs the full network
-// on its two blocks while all four waves share the weight stream through the LDS ring.  Each
+// sum / exclusive product scan over the BS (16 or 32) lanes that hold a block's samples
+template <int BS>
+__device__ __forceinline__ float block_sum(float v) {
+    if constexpr (BS == 32) return lower_half_sum(v);
+    v += dpp_f<0xB1>(0.f, v);
+    v += dpp_f<0x4E>(0.f, v);
+    v += dpp_f<0x141>(0.f, v);
+    v += dpp_f<0x140>(0.f, v);                 // every lane of a 16-lane row holds the row sum
+    return readlane_f<0>(v);
+}
+template <int BS>
+__device__ __forceinline__ float block_excl_prod(float f, int c, float *total) {
+    if constexpr (BS == 32) return lower_half_excl_prod(f, c, total);
+    float v = f;
+    v *= dpp_f<0x111>(1.f, v);
+    v *= dpp_f<0x112>(1.f, v);
+    v *= dpp_f<0x114>(1.f, v);
+    v *= dpp_f<0x118>(1.f, v);                 // inclusive within the 16-lane row
+    *total = readlane_f<15>(v);
+    const float ex = dpp_f<0x138>(1.f, v);     // shift the wave right by one lane
+    return c == 0 ? 1.0f : ex;
+}
+
+// Work unit: a block of BS = 16 CB consecutive samples of one ray (rays are padded to bpr
+// blocks).  A pass of the workgroup covers kFusedWaves blocks, one per wave: every wave runs the
+// full network on its block while all waves share the weight stream through the LDS ring.  Each
 // block is composited on its own with entry transmittance 1 and leaves a record (exit
-// transmittance + weighted sums); combine_kernel chains the records of a ray.
-// NT_FEAT_*: stream units of the feature operand per row block (2 x its k-tiles; 0 = no features)
-template <int NT_FEAT_S, bool DYN, int NT_FEAT_D>
+// transmittance + weighted sums); the records of a ray are chained in the pass itself when the
+// pass holds whole rays (a.rays_per_pass > 0: wave w has block w % bpr of ray
+// pass * rays_per_pass + w / bpr, waves beyond rays_per_pass * bpr idle), otherwise (dense
+// passes, wave w has block pass * kFusedWaves + w) by fused_combine_kernel from HBM.
+// NT_FEAT_*: stream tiles of the feature operand per row block (2 x its k-tiles; 0 = no features)
 #ifndef ZEST_FUSED_WG_PER_CU
 #define ZEST_FUSED_WG_PER_CU 1
 #endif
+template <int EP, int NT_FEAT_S, bool DYN, int NT_FEAT_D>
 __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_CU / 4) void fused_blocks_kernel(FusedArgs a) {
     constexpr bool MOD_S = NT_FEAT_S > 0, MOD_D = NT_FEAT_D > 0;
-    constexpr int NB = kFusedNB;
-    constexpr int UNITS_S = stream_units(4, NT_FEAT_S), UNITS_D = DYN ? stream_units(6, NT_FEAT_D) : 0;
+    constexpr int NP = ep_parts(EP), CB = fused_cb(EP), BS = 16 * CB;
+    constexpr int UNITS_S = stream_units(4, NT_FEAT_S, NP), UNITS_D = DYN ? stream_units(6, NT_FEAT_D, NP) : 0;
     using Ring = RingTiles<kFusedWaves, UNITS_S, UNITS_D>;
     // LDS: weight ring | cameras of both nets | per-lane (z, dist) of the pass's samples
     __shared__ __attribute__((aligned(16))) char lds[kRingUnits * 1024 + 2 * kMaxViews * kCamStride * 4 +
-                                                     kFusedWaves * NB * 32 * 8 + 2 * kSlots * 4 +
-                                                     kFusedWaves * NB * kPartialFloats * 4];
+                                                     kFusedWaves * 32 * 8 + 2 * kSlots * 4 +
+                                                     kFusedWaves * kPartialFloats * 4];
     float *cams_s = reinterpret_cast<float *>(lds + kRingUnits * 1024), *cams_d = cams_s + kMaxViews * kCamStride;
     float2 *zd_lds = reinterpret_cast<float2 *>(cams_d + kMaxViews * kCamStride);
     stage_cams(a.st, cams_s);
     if (DYN) stage_cams(a.dy, cams_d);
-    int *ring_flags = reinterpret_cast<int *>(zd_lds + kFusedWaves * NB * 32);
-    float *rec_lds = reinterpret_cast<float *>(ring_flags + 2 * kSlots);      // [waves * NB][kPartialFloats]
+    int *ring_flags = reinterpret_cast<int *>(zd_lds + kFusedWaves * 32);
+    float *rec_lds = reinterpret_cast<float *>(ring_flags + 2 * kSlots);      // [waves][kPartialFloats]
 #ifdef ZEST_RING_FLAGS
     Ring::init_flags(ring_flags);
 #endif
     __syncthreads();
 
-    const int lane = threadIdx.x & 63, col = lane & 15, grp = lane >> 4, c32 = lane & 31;
+    const int lane = threadIdx.x & 63, col = lane & 15, grp = lane >> 4, cbs = lane & (BS - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const Ring tiles{lds, (gptr_u4)a.st.tiles, (gptr_u4)a.dy.tiles, lane, grp, wave,
                      (unsigned)(wave * Ring::kPieces * 64 + lane) * 16u,
@@ -263,17 +292,29 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
     tiles.prologue();
 
     const int n_blocks = a.R * a.bpr;
-    const int n_pass = (n_blocks + kFusedWaves * NB - 1) / (kFusedWaves * NB);
-    // A lane's samples (column block cb = 2 nb + h: sample 16 h + col of block nb) are re-read
-    // from global memory (L1/L2 hits) wherever they are needed instead of being held in
-    // registers across the network: the engine needs the registers more.
-    auto fetch = [&](int pass, int cb, BlockSamples &b, const float *&dir) {
-        const int g = (pass * kFusedWaves + wave) * NB + cb / 2;
-        const int r = g < n_blocks ? g / a.bpr : 0, s = (g % a.bpr) * 32 + 16 * (cb & 1) + col;
-        b.valid = g < n_blocks && s < a.S;
+    const int n_pass = a.rays_per_pass > 0 ? (a.R + a.rays_per_pass - 1) / a.rays_per_pass
+                                           : (n_blocks + kFusedWaves - 1) / kFusedWaves;
+    // this wave's block in pass `pass` (-1: none)
+    auto block_of = [&](int pass) {
+        int g;
+        if (a.rays_per_pass > 0) {
+            const int ray = pass * a.rays_per_pass + wave / a.bpr;
+            g = (wave < a.rays_per_pass * a.bpr && ray < a.R) ? ray * a.bpr + wave % a.bpr : -1;
+        } else {
+            g = pass * kFusedWaves + wave;
+            if (g >= n_blocks) g = -1;
+        }
+        return __builtin_amdgcn_readfirstlane(g);
+    };
+    // A lane's samples (column block cb: sample 16 cb + col of the block) are re-read from
+    // global memory (L1/L2 hits) wherever they are needed instead of being held in registers
+    // across the network: the engine needs the registers more.
+    auto fetch = [&](int g, int cb, BlockSamples &b) {
+        const int r = g >= 0 ? g / a.bpr : 0, s = (g >= 0 ? g % a.bpr : 0) * BS + 16 * cb + col;
+        b.valid = g >= 0 && s < a.S;
         b.x[0] = b.x[1] = b.x[2] = 0.f, b.x[3] = a.frame_idx;
         b.pw[0] = b.pw[1] = b.pw[2] = 0.f, b.zz = 0.f, b.dist = 0.f;
-        dir = a.dir + 3 * r;
+        const float *dir = a.dir + 3 * r;
         if (b.valid) {
             const size_t m = (size_t)r * a.S + s;
             const float *zr = a.z + (size_t)r * a.S;
@@ -284,11 +325,15 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
             b.dist = ((s + 1 < a.S) ? (zr[s + 1] - b.zz) : 1e10f) * dnorm;
         }
     };
-    // value of column block 2 nb on lanes 0-15 and of 2 nb + 1 on lanes 0-15 -> the block's 32
-    // samples on lanes 0-31 (v_permlane16_swap: row 1 of the first operand <-> row 0 of the second)
-    auto join = [](float lo, float hi) {
-        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
-        return __uint_as_float(r[0]);
+    // a value of the block's samples: column block 0 on lanes 0-15 of `lo`, column block 1 on lanes
+    // 0-15 of `hi` -> lanes 0-31 (v_permlane16_swap: row 1 of the first operand <-> row 0 of the second)
+    auto join = [](const f32x4 (&t)[CB], int i) {
+        if constexpr (CB == 1) {
+            return t[0][i];
+        } else {
+            const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(t[0][i]), __float_as_uint(t[CB - 1][i]), false, false);
+            return __uint_as_float(r[0]);
+        }
     };
 #ifdef ZEST_STAMPS
     unsigned long long st_enc = 0, st_eng = 0, st_comp = 0, st_n = 0;
@@ -297,7 +342,6 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
 #else
 #define ZEST_STAMP(var) do {} while (0)
 #endif
-    constexpr int CB = 2 * NB;
     // Pass order.  blockIdx % 8 labels the workgroups that share an XCD (and its L2): each label
     // takes a contiguous run of passes, so the rays whose gathers touch neighbouring voxels and
     // pixels (whole-image loops render contiguous pixel runs) meet in one L2 instead of being
@@ -317,75 +361,67 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
         unsigned long long st_last = __builtin_amdgcn_s_memtime();
         st_n++;
 #endif
+        const int g = block_of(pass);
         int unit = 0;
         f32x4 head_s[CB], rgb_s[CB], head_d[CB], rgb_d[CB];
         // direction operand of net `n`, built when the engine reaches the view layer
         auto views_of = [&](const FusedNet &n, const float *cams) {
-            return [&, cams](OpArr<1> (&views)[CB]) {
+            return [&, cams](OpArr<1, NP> (&views)[CB]) {
+                const float *dir = a.dir + 3 * (g >= 0 ? g / a.bpr : 0);
+                float dv[4] = {0.f, 0.f, 0.f, 0.f};
+                zest_view_dir(dir, n.w2cs ? cams : nullptr, dv);
+                encode_pe_operand<EP, 3, 4, 1>(dv, grp, views[0]);
 #pragma unroll
-                for (int nb = 0; nb < NB; nb++) {
-                    const int g = (pass * kFusedWaves + wave) * NB + nb;
-                    const float *dir = a.dir + 3 * (g < n_blocks ? g / a.bpr : 0);
-                    float dv[4] = {0.f, 0.f, 0.f, 0.f};
-                    zest_view_dir(dir, n.w2cs ? cams : nullptr, dv);
-                    encode_pe_operand<3, 4, 1>(dv, grp, views[2 * nb]);
-                    views[2 * nb + 1] = views[2 * nb];         // one ray per block
-                }
+                for (int cb = 1; cb < CB; cb++) views[cb] = views[0];          // one ray per block
             };
         };
         {
-            OpArr<2> pts_s[CB];
-            OpArr<NT_FEAT_S / 2> feat_s[CB];
+            OpArr<2, NP> pts_s[CB];
+            OpArr<NT_FEAT_S / 2, NP> feat_s[CB];
 #pragma unroll
             for (int cb = 0; cb < CB; cb++) {
                 BlockSamples b;
-                const float *dir;
-                fetch(pass, cb, b, dir);
+                fetch(g, cb, b);
                 // compositing needs z and the sample spacing after the engine: park them in LDS so
                 // that phase issues no global load (a vmcnt wait there would drain the weight DMA)
-                if (grp == 0) zd_lds[(wave * NB + cb / 2) * 32 + 16 * (cb & 1) + col] = make_float2(b.zz, b.valid ? b.dist : -1.0f);
+                if (grp == 0) zd_lds[wave * 32 + 16 * cb + col] = make_float2(b.zz, b.valid ? b.dist : -1.0f);
 #ifdef ZEST_EXPERIMENT_NO_ENCODE        // timing experiment only
 #pragma unroll
-                for (int t = 0; t < 2; t++) pts_s[cb].t[t] = bf16x8{(short)lane, 1, 2, 3, 4, 5, 6, 7};
+                for (int t = 0; t < 2; t++) pts_s[cb].t[0][t] = bf16x8{(short)lane, 1, 2, 3, 4, 5, 6, 7};
 #else
-                encode_pe_operand<3, 10, 2>(b.x, grp, pts_s[cb]);
+                encode_pe_operand<EP, 3, 10, 2>(b.x, grp, pts_s[cb]);
 #endif
-                if constexpr (MOD_S) encode_feat_operand<NT_FEAT_S / 2>(a.st, cams_s, b.x, b.pw, grp, b.valid, feat_s[cb]);
+                if constexpr (MOD_S) encode_feat_operand<EP, NT_FEAT_S / 2>(a.st, cams_s, b.x, b.pw, grp, b.valid, feat_s[cb]);
             }
             ZEST_STAMP(st_enc);
-            engine_forward<NB, 4, MOD_S, NT_FEAT_S>(tiles, unit, a.st.v2 != 0, pts_s, feat_s,
-                                                    views_of(a.st, cams_s), head_s, rgb_s);
+            engine_forward<EP, CB, 4, MOD_S, NT_FEAT_S>(tiles, unit, a.st.v2 != 0, pts_s, feat_s,
+                                                        views_of(a.st, cams_s), head_s, rgb_s);
             ZEST_STAMP(st_eng);
         }
         if (DYN) {
-            OpArr<3> pts_d[CB];
-            OpArr<NT_FEAT_D / 2> feat_d[CB];
+            OpArr<3, NP> pts_d[CB];
+            OpArr<NT_FEAT_D / 2, NP> feat_d[CB];
 #pragma unroll
             for (int cb = 0; cb < CB; cb++) {
                 BlockSamples b;
-                const float *dir;
-                fetch(pass, cb, b, dir);
-                encode_pe_operand<4, 10, 3>(b.x, grp, pts_d[cb]);
-                if constexpr (MOD_D) encode_feat_operand<NT_FEAT_D / 2>(a.dy, cams_d, b.x, b.pw, grp, b.valid, feat_d[cb]);
+                fetch(g, cb, b);
+                encode_pe_operand<EP, 4, 10, 3>(b.x, grp, pts_d[cb]);
+                if constexpr (MOD_D) encode_feat_operand<EP, NT_FEAT_D / 2>(a.dy, cams_d, b.x, b.pw, grp, b.valid, feat_d[cb]);
             }
             ZEST_STAMP(st_enc);
-            engine_forward<NB, 6, MOD_D, NT_FEAT_D>(tiles, unit, false, pts_d, feat_d,
-                                                    views_of(a.dy, cams_d), head_d, rgb_d);
+            engine_forward<EP, CB, 6, MOD_D, NT_FEAT_D>(tiles, unit, false, pts_d, feat_d,
+                                                        views_of(a.dy, cams_d), head_d, rgb_d);
             ZEST_STAMP(st_eng);
         }
-        // ---- per-block compositing on lanes 0-31 (sample = lane): rgb rows 0-2, head rows 0, 1
+        // ---- per-block compositing on lanes 0 .. BS-1 (sample = lane): rgb rows 0-2, head rows 0, 1
         // sit in elements 0-2 / 0, 1 of lane group 0 of each column block
-#pragma unroll
-        for (int nb = 0; nb < NB; nb++) {
+        {
             BlockSamples b;
-            const int g_ = (pass * kFusedWaves + wave) * NB + nb;
-            const int gidx = g_ < n_blocks ? g_ : -1;
             {
-                const float2 zd = zd_lds[(wave * NB + nb) * 32 + c32];
+                const float2 zd = zd_lds[wave * 32 + cbs];
                 b.zz = zd.x, b.dist = fmaxf(zd.y, 0.0f), b.valid = zd.y >= 0.0f;
             }
-            float cr = join(rgb_s[2 * nb][0], rgb_s[2 * nb + 1][0]), cg = join(rgb_s[2 * nb][1], rgb_s[2 * nb + 1][1]),
-                  cb = join(rgb_s[2 * nb][2], rgb_s[2 * nb + 1][2]), sg = join(head_s[2 * nb][0], head_s[2 * nb + 1][0]);
+            float cr = join(rgb_s, 0), cg = join(rgb_s, 1), cb = join(rgb_s, 2), sg = join(head_s, 0);
             if (a.st.v2) {   // 'v2' nets activate inside the network; the compositor does it again
                 cr = zest_sigmoid(cr), cg = zest_sigmoid(cg), cb = zest_sigmoid(cb), sg = fmaxf(sg, 0.f);
             }
@@ -396,54 +432,48 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
             for (int i = 0; i < kPartialFloats; i++) rec[i] = 0.f;
             {
                 float tot;
-                const float w = al_s * lower_half_excl_prod(1.0f - al_s + 1e-10f, c32, &tot);
+                const float w = al_s * block_excl_prod<BS>(1.0f - al_s + 1e-10f, cbs, &tot);
                 rec[0] = tot;
-                rec[1] = lower_half_sum(w * cr), rec[2] = lower_half_sum(w * cg), rec[3] = lower_half_sum(w * cb);
-                rec[4] = lower_half_sum(w * b.zz), rec[5] = lower_half_sum(w);
+                rec[1] = block_sum<BS>(w * cr), rec[2] = block_sum<BS>(w * cg), rec[3] = block_sum<BS>(w * cb);
+                rec[4] = block_sum<BS>(w * b.zz), rec[5] = block_sum<BS>(w);
             }
             if (DYN) {
-                const float blend = zest_sigmoid(join(head_s[2 * nb][1], head_s[2 * nb + 1][1]));
-                const float er = zest_sigmoid(join(rgb_d[2 * nb][0], rgb_d[2 * nb + 1][0])),
-                            eg = zest_sigmoid(join(rgb_d[2 * nb][1], rgb_d[2 * nb + 1][1])),
-                            eb = zest_sigmoid(join(rgb_d[2 * nb][2], rgb_d[2 * nb + 1][2]));
-                const float sg_d = join(head_d[2 * nb][0], head_d[2 * nb + 1][0]);
+                const float blend = zest_sigmoid(join(head_s, 1));
+                const float er = zest_sigmoid(join(rgb_d, 0)), eg = zest_sigmoid(join(rgb_d, 1)),
+                            eb = zest_sigmoid(join(rgb_d, 2));
+                const float sg_d = join(head_d, 0);
                 const float a_fg = b.valid ? 1.0f - expf(-fmaxf(sg_d, 0.f) * b.dist) : 0.0f;
                 const float a_d = a_fg * blend, a_st = al_s * (1.0f - blend);
                 float tot_b, tot_f;
-                const float Tb = lower_half_excl_prod((1.0f - a_d) * (1.0f - a_st) + 1e-10f, c32, &tot_b);
-                const float wf = a_fg * lower_half_excl_prod(1.0f - a_fg + 1e-10f, c32, &tot_f);
+                const float Tb = block_excl_prod<BS>((1.0f - a_d) * (1.0f - a_st) + 1e-10f, cbs, &tot_b);
+                const float wf = a_fg * block_excl_prod<BS>(1.0f - a_fg + 1e-10f, cbs, &tot_f);
                 const float wd = Tb * a_d, ws = Tb * a_st;
                 rec[6] = tot_b;
-                rec[7] = lower_half_sum(wd * er + ws * cr), rec[8] = lower_half_sum(wd * eg + ws * cg);
-                rec[9] = lower_half_sum(wd * eb + ws * cb), rec[10] = lower_half_sum((wd + ws) * b.zz);
-                rec[11] = lower_half_sum(wd);
+                rec[7] = block_sum<BS>(wd * er + ws * cr), rec[8] = block_sum<BS>(wd * eg + ws * cg);
+                rec[9] = block_sum<BS>(wd * eb + ws * cb), rec[10] = block_sum<BS>((wd + ws) * b.zz);
+                rec[11] = block_sum<BS>(wd);
                 rec[12] = tot_f;
-                rec[13] = lower_half_sum(wf * er), rec[14] = lower_half_sum(wf * eg), rec[15] = lower_half_sum(wf * eb);
-                rec[16] = lower_half_sum(wf * b.zz);
+                rec[13] = block_sum<BS>(wf * er), rec[14] = block_sum<BS>(wf * eg), rec[15] = block_sum<BS>(wf * eb);
+                rec[16] = block_sum<BS>(wf * b.zz);
             }
-            if (lane == 0 && gidx >= 0) {
+            if (lane == 0 && g >= 0) {
                 // records go to HBM for combine_kernel, or stay in LDS when the pass holds whole rays
-                float4 *o = a.combine_in_kernel
-                                ? reinterpret_cast<float4 *>(rec_lds + (wave * NB + nb) * kPartialFloats)
-                                : reinterpret_cast<float4 *>(a.partials + (size_t)gidx * kPartialFloats);
+                float4 *o = a.rays_per_pass > 0 ? reinterpret_cast<float4 *>(rec_lds + wave * kPartialFloats)
+                                                : reinterpret_cast<float4 *>(a.partials + (size_t)g * kPartialFloats);
 #pragma unroll
                 for (int i = 0; i < (DYN ? 5 : 2); i++)
                     o[i] = make_float4(rec[4 * i], rec[4 * i + 1], rec[4 * i + 2], rec[4 * i + 3]);
             }
         }
-        if (a.combine_in_kernel) {
+        if (a.rays_per_pass > 0) {
             // The blocks of a ray sit in consecutive waves of this pass: after one rendezvous the
             // wave holding a ray's first block chains the records (80 B each, in LDS) and writes
             // the ray's maps - no record traffic, no second launch.  The next pass cannot reach
             // this point before every wave has passed the ring's chunk barriers, i.e. has left it.
             __syncthreads();
-#pragma unroll
-            for (int nb = 0; nb < NB; nb++) {
-                const int slot = wave * NB + nb, g_ = pass * (kFusedWaves * NB) + slot;
-                if (lane == 0 && g_ < n_blocks && g_ % a.bpr == 0)
-                    combine_ray([&](int b) { return rec_lds + (slot + b) * kPartialFloats; }, a.bpr, DYN,
-                                a.white_bkgd, a.out + (size_t)(g_ / a.bpr) * 16);
-            }
+            if (lane == 0 && g >= 0 && g % a.bpr == 0)
+                combine_ray([&](int b) { return rec_lds + (wave + b) * kPartialFloats; }, a.bpr, DYN,
+                            a.white_bkgd, a.out + (size_t)(g / a.bpr) * 16);
         }
         ZEST_STAMP(st_comp);
         tiles.next_pass();
@@ -465,21 +495,21 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
 }
 
 // one translation unit per variant (fused_*.hip) so they compile in parallel
-#define ZEST_FUSED_VARIANT(tag, NTS, DYN, NTD)                                                   \
-    int fused_launch_##tag(const FusedArgs &a, int blocks, hipStream_t stream) {                 \
-        hipLaunchKernelGGL((fused_blocks_kernel<NTS, DYN, NTD>), dim3(blocks),                   \
+#define ZEST_FUSED_VARIANT(ptag, EP, tag, NTS, DYN, NTD) ZEST_FUSED_VARIANT_(ptag, EP, tag, NTS, DYN, NTD)
+#define ZEST_FUSED_VARIANT_(ptag, EP, tag, NTS, DYN, NTD)                                        \
+    int fused_launch_##ptag##_##tag(const FusedArgs &a, int blocks, hipStream_t stream) {        \
+        hipLaunchKernelGGL((fused_blocks_kernel<EP, NTS, DYN, NTD>), dim3(blocks),               \
                            dim3(kFusedWaves * 64), 0, stream, a);                                \
-        ZEST_RETURN_LAUNCH("zest_render_fused_fwd(" #tag ")");                                   \
+        ZEST_RETURN_LAUNCH("zest_render_fused_fwd(" #ptag "_" #tag ")");                         \
     }                                                                                            \
-    int fused_wg_per_cu_##tag() { return ZEST_FUSED_WG_PER_CU; }                                 \
-    int fused_units_##tag(int which) {                                                           \
-        return which == 0 ? stream_units(4, NTS) : (DYN ? stream_units(6, NTD) : 0);             \
+    int fused_units_##ptag##_##tag(int which) {                                                  \
+        return which == 0 ? stream_units(4, NTS, ep_parts(EP)) : (DYN ? stream_units(6, NTD, ep_parts(EP)) : 0); \
     }
 
-#define ZEST_FUSED_DECL(tag)                                                    \
-    int fused_launch_##tag(const FusedArgs &a, int blocks, hipStream_t stream); \
-    int fused_units_##tag(int which);                                           \
-    int fused_wg_per_cu_##tag();
+#define ZEST_FUSED_DECL1(ptag, tag)                                                     \
+    int fused_launch_##ptag##_##tag(const FusedArgs &a, int blocks, hipStream_t stream); \
+    int fused_units_##ptag##_##tag(int which);
+#define ZEST_FUSED_DECL(tag) ZEST_FUSED_DECL1(bf16, tag) ZEST_FUSED_DECL1(f16, tag) ZEST_FUSED_DECL1(x3, tag)
 ZEST_FUSED_DECL(s0)
 ZEST_FUSED_DECL(s2)
 ZEST_FUSED_DECL(s4)

@@ -20,13 +20,13 @@ __global__ void fused_combine_kernel(const float *__restrict__ partials, int R, 
 
 namespace {
 
-bool fill_net(const zest_mlp_desc *d, const void *packed, const zest_view_set *vs, int pts_ch,
+bool fill_net(const zest_mlp_desc *d, const void *packed, const zest_view_set *vs, int pts_ch, int precision,
               zest::FusedNet *n, int *nt_feat, int *units, const char **err) {
     memset(n, 0, sizeof(*n));
     if (!d || !packed) return *err = "descriptor and packed weights are required", false;
     if (d->in_ch_pts != pts_ch) return *err = "unexpected in_ch_pts for this slot", false;
     zest::MlpPlan plan;
-    if (!zest::build_plan(*d, ZEST_PREC_BF16, zest::ORDER_ACC, &plan, err, false)) return false;
+    if (!zest::build_plan(*d, precision, zest::ORDER_ACC, &plan, err, false)) return false;
     n->bias = (const float *)packed;
     n->tiles = (const uint4 *)((const char *)packed + plan.bias_bytes);
     n->head = d->head, n->v2 = d->net_type == 2;
@@ -61,9 +61,18 @@ constexpr size_t kStampBytes = 1024 * 8 * 8 * 8;       // diagnostic builds: 8 u
 constexpr size_t kStampBytes = 0;
 #endif
 
+static int g_pass_shape = 0;       // 0: chosen per launch, 1: dense passes, 2: ray-aligned passes
+
+extern "C" int zest_render_fused_set_passes(int shape) {
+    ZEST_CHECK_ARG(shape >= 0 && shape <= 2, "zest_render_fused_set_passes: shape must be 0 (auto), 1 (dense) or 2 (aligned)");
+    g_pass_shape = shape;
+    return 0;
+}
+
 extern "C" size_t zest_render_fused_workspace(int R, int S) {
     if (R <= 0 || S <= 0) return 16 + kStampBytes;
-    return (size_t)R * ((S + 31) / 32) * zest::kPartialFloats * sizeof(float) + kStampBytes;
+    // one record per block of a ray; the smallest block (split-fp16 operands) is 16 samples
+    return (size_t)R * ((S + 15) / 16) * zest::kPartialFloats * sizeof(float) + kStampBytes;
 }
 
 extern "C" int zest_render_fused_fwd(const float *ndc, const float *pts, const float *z,
@@ -78,25 +87,26 @@ extern "C" int zest_render_fused_fwd(const float *ndc, const float *pts, const f
                    "zest_render_fused_fwd: ndc, z, rays_dir, workspace, out required");
     ZEST_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "zest_render_fused_fwd: workspace must be 16-byte aligned");
     ZEST_CHECK_ARG(R >= 0 && S >= 1, "zest_render_fused_fwd: bad shape R=%d S=%d", R, S);
-    ZEST_CHECK_ARG(precision == ZEST_PREC_BF16,
-                   "zest_render_fused_fwd: the fused renderer is the bf16 engine; use the per-op "
-                   "entry points for fp32");
+    ZEST_CHECK_ARG(zest::prec_is_engine(precision),
+                   "zest_render_fused_fwd: precision must be ZEST_PREC_BF16, _F16 or _F16X3 (the exact-product "
+                   "fp32 kernel exists per operator only: zest_mlp_fwd)");
     ZEST_CHECK_ARG(((uintptr_t)out & 15) == 0, "zest_render_fused_fwd: out must be 16-byte aligned");
     zest::FusedArgs a;
     memset(&a, 0, sizeof(a));
     a.ndc = ndc, a.pts = pts, a.z = z, a.dir = rays_dir, a.R = R, a.S = S;
     a.frame_idx = frame_idx, a.white_bkgd = white_bkgd, a.out = out;
-    a.bpr = (S + 31) / 32, a.partials = (float *)workspace;
+    const int bs = 16 * zest::fused_cb(precision);                    // samples per block
+    a.bpr = (S + bs - 1) / bs, a.partials = (float *)workspace;
 #ifdef ZEST_STAMPS
-    a.stamps = (unsigned long long *)((char *)workspace + (size_t)R * a.bpr * zest::kPartialFloats * sizeof(float));
+    a.stamps = (unsigned long long *)((char *)workspace + zest_render_fused_workspace(R, S) - kStampBytes);
 #endif
     const char *err = nullptr;
     int nts = 0, ntd = 0, units_s = 0, units_d = 0;
-    ZEST_CHECK_ARG(fill_net(desc_static, packed_static, views_static, 63, &a.st, &nts, &units_s, &err),
+    ZEST_CHECK_ARG(fill_net(desc_static, packed_static, views_static, 63, precision, &a.st, &nts, &units_s, &err),
                    "zest_render_fused_fwd: static net: %s", err);
     const bool dyn = desc_dynamic != nullptr;
     if (dyn) {
-        ZEST_CHECK_ARG(fill_net(desc_dynamic, packed_dynamic, views_dynamic, 84, &a.dy, &ntd, &units_d, &err),
+        ZEST_CHECK_ARG(fill_net(desc_dynamic, packed_dynamic, views_dynamic, 84, precision, &a.dy, &ntd, &units_d, &err),
                        "zest_render_fused_fwd: dynamic net: %s", err);
         ZEST_CHECK_ARG(desc_static->head == ZEST_HEAD_BLEND && desc_dynamic->head == ZEST_HEAD_DYNAMIC,
                        "zest_render_fused_fwd: blending needs a static net with the blend head and "
@@ -108,22 +118,33 @@ extern "C" int zest_render_fused_fwd(const float *ndc, const float *pts, const f
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         cus = 256;
-    const int n_pass = zest_div_up((long long)R * a.bpr, zest::kFusedWaves * zest::kFusedNB);
-    // whole rays per pass (bpr divides the pass's blocks: S <= 32, 64, 128 or 256 with 8 waves):
-    // the kernel finishes the rays itself and the combine launch is skipped
-    a.combine_in_kernel = (zest::kFusedWaves * zest::kFusedNB) % a.bpr == 0 ? 1 : 0;
-    int blocks = cus;                                               // set per variant below
+    // Pass shape.  Dense: the blocks of all rays in order, kFusedWaves per pass, block records to
+    // the workspace and a second tiny launch chains them.  Ray-aligned: a pass holds
+    // kFusedWaves / bpr whole rays and finishes them itself (no record traffic, no second launch);
+    // waves beyond that idle.  Aligned is taken when it costs no extra round of passes on this
+    // device (always when bpr divides kFusedWaves: S <= 32, 64, 128, 256 for 32-sample blocks).
+    const int W = zest::kFusedWaves;
+    const int dense_pass = zest_div_up((long long)R * a.bpr, W);
+    const int rpp = a.bpr <= W ? W / a.bpr : 0;
+    const int aligned_pass = rpp ? zest_div_up(R, rpp) : 0;
+    a.rays_per_pass = (rpp && zest_div_up(aligned_pass, cus) <= zest_div_up(dense_pass, cus)) ? rpp : 0;
+    if (g_pass_shape == 1) a.rays_per_pass = 0;            // zest_render_fused_set_passes: dense
+    if (g_pass_shape == 2) a.rays_per_pass = rpp;          // ray-aligned wherever a ray fits a pass
+    const int n_pass = a.rays_per_pass ? aligned_pass : dense_pass;
+    const int blocks = n_pass < cus ? n_pass : cus;                 // one workgroup per CU (128 KiB ring)
     hipStream_t st = (hipStream_t)stream;
     const int key = (dyn ? 100 : 0) + nts * 10 + ntd;
     int rc = -1;
+#define ZEST_CASE1(ptag, tag)                                                                    \
+    ZEST_CHECK_ARG(zest::fused_units_##ptag##_##tag(0) == units_s && zest::fused_units_##ptag##_##tag(1) == units_d, \
+                   "zest_render_fused_fwd: packed stream is %d+%d units, kernel expects %d+%d",  \
+                   units_s, units_d, zest::fused_units_##ptag##_##tag(0), zest::fused_units_##ptag##_##tag(1)); \
+    rc = zest::fused_launch_##ptag##_##tag(a, blocks, st);
 #define ZEST_CASE(k, tag)                                                                        \
     case k:                                                                                      \
-        ZEST_CHECK_ARG(zest::fused_units_##tag(0) == units_s && zest::fused_units_##tag(1) == units_d, \
-                       "zest_render_fused_fwd: packed stream is %d+%d units, kernel expects %d+%d",  \
-                       units_s, units_d, zest::fused_units_##tag(0), zest::fused_units_##tag(1));    \
-        blocks = cus * zest::fused_wg_per_cu_##tag();                                            \
-        if (n_pass < blocks) blocks = n_pass;                                                    \
-        rc = zest::fused_launch_##tag(a, blocks, st);                                            \
+        if (precision == ZEST_PREC_BF16) { ZEST_CASE1(bf16, tag) }                               \
+        else if (precision == ZEST_PREC_F16) { ZEST_CASE1(f16, tag) }                            \
+        else { ZEST_CASE1(x3, tag) }                                                             \
         break;
     switch (key) {
         ZEST_CASE(0, s0)
@@ -140,7 +161,8 @@ extern "C" int zest_render_fused_fwd(const float *ndc, const float *pts, const f
             return (int)hipErrorInvalidValue;
     }
 #undef ZEST_CASE
-    if (rc != 0 || a.combine_in_kernel) return rc;
+#undef ZEST_CASE1
+    if (rc != 0 || a.rays_per_pass) return rc;
     hipLaunchKernelGGL(zest::fused_combine_kernel, dim3(zest_div_up(R, 128)), dim3(128), 0, st,
                        a.partials, R, a.bpr, dyn ? 1 : 0, white_bkgd, out);
     ZEST_RETURN_LAUNCH("zest_render_fused_fwd(combine)");

@@ -20,6 +20,7 @@ using zest::MlpPlan;
 struct DevPlan {
     MlpPlan plan;
     uint32_t *tile_src = nullptr, *bias_src = nullptr, *hdr_src = nullptr;   // device gather tables
+    uint8_t *unit_part = nullptr;                                            // device: hi / lo flag per unit
 };
 
 std::mutex g_mu;
@@ -44,8 +45,10 @@ DevPlan *get_plan(const zest_mlp_desc &d, int precision, int order, bool need_ta
     }
     if (need_tables && !dp->tile_src) {
         const size_t nt = dp->plan.tile_src.size() * 4, nb = dp->plan.bias_src.size() * 4;
-        const size_t nh = dp->plan.hdr_src.size() * 4;
+        const size_t nh = dp->plan.hdr_src.size() * 4, np = dp->plan.unit_part.size();
         hipError_t e = hipMalloc(&dp->tile_src, nt);
+        if (e == hipSuccess) e = hipMalloc(&dp->unit_part, np ? np : 4);
+        if (e == hipSuccess && np) e = hipMemcpy(dp->unit_part, dp->plan.unit_part.data(), np, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMalloc(&dp->bias_src, nb ? nb : 4);
         if (e == hipSuccess) e = hipMalloc(&dp->hdr_src, nh ? nh : 4);
         if (e == hipSuccess) e = hipMemcpy(dp->tile_src, dp->plan.tile_src.data(), nt, hipMemcpyHostToDevice);
@@ -61,16 +64,19 @@ DevPlan *get_plan(const zest_mlp_desc &d, int precision, int order, bool need_ta
 }
 
 inline int order_for(int precision) {
-    return precision == ZEST_PREC_BF16 ? zest::ORDER_ACC : zest::ORDER_NATURAL;
+    return zest::prec_is_engine(precision) ? zest::ORDER_ACC : zest::ORDER_NATURAL;
 }
 
 struct ParamTable {
     const float *p[2 * ZEST_P_COUNT];
 };
 
-template <bool BF16>
+// PREC: element type of the packed tiles.  ZEST_PREC_F16X3: a unit flagged 1 in unit_part holds
+// the scaled remainders fp16((w - fp16(w)) * 2^11) of the unit in front of it.
+template <int PREC>
 __global__ void pack_kernel(ParamTable pt, const uint32_t *__restrict__ tile_src, size_t n_w,
                             const uint32_t *__restrict__ bias_src, size_t n_b,
+                            const uint8_t *__restrict__ unit_part,
                             float *__restrict__ bias_out, void *__restrict__ w_out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_b) {
@@ -80,10 +86,16 @@ __global__ void pack_kernel(ParamTable pt, const uint32_t *__restrict__ tile_src
     if (i < n_w) {
         const uint32_t s = tile_src[i];
         const float v = s == 0xFFFFFFFFu ? 0.0f : pt.p[2 * (s >> 24)][s & 0xFFFFFF];
-        if (BF16)
+        if (PREC == ZEST_PREC_BF16) {
             ((__hip_bfloat16 *)w_out)[i] = __float2bfloat16(v);
-        else
+        } else if (PREC == ZEST_PREC_F16) {
+            ((_Float16 *)w_out)[i] = (_Float16)v;
+        } else if (PREC == ZEST_PREC_F16X3) {
+            const _Float16 hi = (_Float16)v;
+            ((_Float16 *)w_out)[i] = unit_part[i / 512] ? (_Float16)((v - (float)hi) * 2048.0f) : hi;
+        } else {
             ((float *)w_out)[i] = v;
+        }
     }
 }
 
@@ -253,18 +265,21 @@ extern "C" int zest_mlp_pack(const zest_mlp_desc *desc, int precision, const flo
     const size_t n_w = p.tile_src.size(), n_b = p.bias_src.size();
     const size_t n = n_w > n_b ? n_w : n_b;
     void *w_out = (char *)packed + p.bias_bytes;
-    if (precision == ZEST_PREC_BF16) {
-        hipLaunchKernelGGL(pack_kernel<true>, dim3(zest_div_up(n, 256)), dim3(256), 0,
-                           (hipStream_t)stream, pt, dp->tile_src, n_w, dp->bias_src, n_b,
-                           (float *)packed, w_out);
+#define ZEST_PACK(PREC)                                                                            \
+    hipLaunchKernelGGL(pack_kernel<PREC>, dim3(zest_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, \
+                       pt, dp->tile_src, n_w, dp->bias_src, n_b, dp->unit_part, (float *)packed, w_out)
+    if (zest::prec_is_engine(precision)) {
+        if (precision == ZEST_PREC_BF16) ZEST_PACK(ZEST_PREC_BF16);
+        else if (precision == ZEST_PREC_F16) ZEST_PACK(ZEST_PREC_F16);
+        else ZEST_PACK(ZEST_PREC_F16X3);
         const size_t n_h = p.hdr_src.size();
-        if (n_h)     // same stream, after the bf16 pass that zero-filled the header units
+        if (n_h)     // same stream, after the tile pass that zero-filled the header units
             hipLaunchKernelGGL(pack_headers_kernel, dim3(zest_div_up(n_h, 256)), dim3(256), 0,
                                (hipStream_t)stream, pt, dp->hdr_src, n_h, (char *)w_out);
-    } else
-        hipLaunchKernelGGL(pack_kernel<false>, dim3(zest_div_up(n, 256)), dim3(256), 0,
-                           (hipStream_t)stream, pt, dp->tile_src, n_w, dp->bias_src, n_b,
-                           (float *)packed, w_out);
+    } else {
+        ZEST_PACK(ZEST_PREC_F32);
+    }
+#undef ZEST_PACK
     ZEST_RETURN_LAUNCH("zest_mlp_pack");
 }
 
@@ -286,5 +301,5 @@ extern "C" int zest_mlp_fwd(const zest_mlp_desc *desc, int precision, const void
                            (hipStream_t)stream, pr, bias, (const float4 *)tiles, x, M, out);
         ZEST_RETURN_LAUNCH("zest_mlp_fwd(f32)");
     }
-    return zest::mlp_bf16_launch(p, tiles, x, M, out, (hipStream_t)stream);
+    return zest::mlp_engine_launch(p, tiles, x, M, out, (hipStream_t)stream);
 }

@@ -1,4 +1,4 @@
-// bf16 MFMA engine for the width-256 NeRF MLP: activations stay in registers.
+// MFMA engine for the width-256 NeRF MLP (bf16 / fp16 / split-fp16 operands): activations stay in registers.
 //
 // Orientation: Y^T = W X^T with v_mfma_f32_16x16x32_bf16 (this kernel is limited by board power,
 // not by issue cycles; at identical operand traffic this shape delivered 5-15 % more FLOP/s
@@ -36,13 +36,14 @@ typedef __attribute__((address_space(3))) int lds_int;                // an int 
 namespace zest {
 
 // units in the stream of one net (mirror of build_plan for ORDER_ACC, checked on the host)
-constexpr int stream_units_raw(int nt_pts, int nt_feat) {
-    const int mod = nt_feat;                       // modulation tiles per row block (0 = off)
-    return 8 * (1 + mod + nt_pts) + 6 * 8 * (1 + mod + 16) + 8 * (1 + mod + nt_pts + 16)   // trunk
-           + (1 + 16) + 8 * (1 + 16) + 4 * (1 + 16 + 2) + (1 + 8);                         // heads
+// (parts: stream units per weight tile, 2 for the split fp16 pair)
+constexpr int stream_units_raw(int nt_pts, int nt_feat, int parts = 1) {
+    const int mod = nt_feat * parts, P = nt_pts * parts, H = 16 * parts;   // mod: modulation units per row block (0 = off)
+    return 8 * (1 + mod + P) + 6 * 8 * (1 + mod + H) + 8 * (1 + mod + P + H)   // trunk
+           + (1 + H) + 8 * (1 + H) + 4 * (1 + H + 2 * parts) + (1 + H / 2);     // heads
 }
-constexpr int stream_units(int nt_pts, int nt_feat) {
-    return (stream_units_raw(nt_pts, nt_feat) + kStreamAlign - 1) / kStreamAlign * kStreamAlign;
+constexpr int stream_units(int nt_pts, int nt_feat, int parts = 1) {
+    return (stream_units_raw(nt_pts, nt_feat, parts) + kStreamAlign - 1) / kStreamAlign * kStreamAlign;
 }
 
 // ---- weight source: LDS ring fed by LDS-DMA -----------------------------------------------
@@ -301,26 +302,88 @@ struct RingTiles {
     __device__ __forceinline__ void drain() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
 
-// two fp32 -> packed bf16 pair (round to nearest even): one v_cvt_pk_bf16_f32.  Written as a
-// vector conversion the compiler understands - an inline-asm form would read MFMA results
-// without the wait states hipcc inserts for its own instructions (cdna guide 5.7 item 2) -
-// and not as __float22bfloat162_rn, which costs 2 cvt + shift + or on MFMA tile elements.
+// ---- operand types ------------------------------------------------------------------------
+// EP (engine precision) is one of ZEST_PREC_BF16 / _F16 / _F16X3 (include/zest_render.h).  A tile
+// of 8 operand values per lane is 4 VGPRs of 2-byte elements (`bf16x8` is used as the raw
+// container for both element types).  ZEST_PREC_F16X3 carries every operand as the pair
+// hi = fp16(v), lo = fp16((v - hi) * 2^11): together 22 significant bits.  The lo part is scaled
+// so that it stays a normal fp16 number wherever hi is one, and the products that contain it
+// are summed in an accumulator of their own that enters the result scaled by 2^-11:
+//     sum_k w_k x_k  ~=  sum hi_w hi_x  +  2^-11 (sum hi_w lo_x + sum lo_w hi_x)
+// (the dropped lo*lo term is 2^-22 relative).  Three MFMAs per product at the fp16 rate instead
+// of one fp32 MFMA at 1/16 of that rate.
+constexpr int ep_parts(int EP) { return EP == ZEST_PREC_F16X3 ? 2 : 1; }
+constexpr float kLoScale = 2048.0f, kLoUnscale = 1.0f / 2048.0f;
+
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+
+// two fp32 -> one register of two 2-byte elements, round to nearest even: one v_cvt_pk_bf16_f32 /
+// v_cvt_pk_f16_f32.  Written as a vector conversion the compiler understands - an inline-asm form
+// would read MFMA results without the wait states hipcc inserts for its own instructions (cdna
+// guide 5.7 item 2) - and not as __float22bfloat162_rn, which costs 2 cvt + shift + or.
+template <int EP>
+__device__ __forceinline__ unsigned pack_pair(float lo, float hi) {
     const f32x2_t f = {lo, hi};
-    const bf16x2_t r = __builtin_convertvector(f, bf16x2_t);
-    return *reinterpret_cast<const unsigned *>(&r);
+    if constexpr (EP == ZEST_PREC_BF16) {
+        const bf16x2_t r = __builtin_convertvector(f, bf16x2_t);
+        return __builtin_bit_cast(unsigned, r);
+    } else {
+        const f16x2_t r = __builtin_convertvector(f, f16x2_t);
+        return __builtin_bit_cast(unsigned, r);
+    }
+}
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) { return pack_pair<ZEST_PREC_BF16>(lo, hi); }
+
+// the (hi, lo) registers of two values (ZEST_PREC_F16X3)
+__device__ __forceinline__ void split_pair(float a, float b, unsigned &hi, unsigned &lo) {
+    const f32x2_t f = {a, b};
+    const f16x2_t h = __builtin_convertvector(f, f16x2_t);
+    const f32x2_t back = __builtin_convertvector(h, f32x2_t);
+    const f32x2_t rem = {(a - back[0]) * kLoScale, (b - back[1]) * kLoScale};     // a - hi is exact in fp32
+    const f16x2_t l = __builtin_convertvector(rem, f16x2_t);
+    hi = __builtin_bit_cast(unsigned, h), lo = __builtin_bit_cast(unsigned, l);
+}
+
+template <int EP>
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    if constexpr (EP == ZEST_PREC_BF16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b),
+                                                      c, 0, 0, 0);
 }
 
 // relu as one v_med3_f32: max(v, 0) for every finite activation (fmaxf costs a second,
-// canonicalising v_max in front; med3 against a finite bound is not folded back into it)
-__device__ __forceinline__ float relu1(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 3.0e38f); }
+// canonicalising v_max in front; med3 against a finite bound is not folded back into it).
+// The fp16 modes take the largest fp16 number as the bound: an activation beyond it saturates
+// instead of turning into infinity (and NaN one layer later).
+template <int EP>
+__device__ __forceinline__ float relu1(float v) {
+    return __builtin_amdgcn_fmed3f(v, 0.0f, EP == ZEST_PREC_BF16 ? 3.0e38f : 65504.0f);
+}
 
-template <int N>
-struct OpArr {              // N k-tiles of one column block's operand; N = 0 allowed
-    bf16x8 t[N > 0 ? N : 1];
+template <int N, int NP = 1>
+struct OpArr {              // N k-tiles of one column block's operand in NP parts (hi [, lo]); N = 0 allowed
+    bf16x8 t[NP][N > 0 ? N : 1];
 };
+
+// eight fp32 values of one lane -> k-tile `k` of an operand
+template <int EP, int N>
+__device__ __forceinline__ void store_tile(const float (&v)[8], OpArr<N, ep_parts(EP)> &op, int k) {
+    if constexpr (EP == ZEST_PREC_F16X3) {
+        uint4 h, l;
+        split_pair(v[0], v[1], h.x, l.x), split_pair(v[2], v[3], h.y, l.y);
+        split_pair(v[4], v[5], h.z, l.z), split_pair(v[6], v[7], h.w, l.w);
+        op.t[0][k] = __builtin_bit_cast(bf16x8, h), op.t[1][k] = __builtin_bit_cast(bf16x8, l);
+    } else {
+        const uint4 q = make_uint4(pack_pair<EP>(v[0], v[1]), pack_pair<EP>(v[2], v[3]), pack_pair<EP>(v[4], v[5]),
+                                   pack_pair<EP>(v[6], v[7]));
+        op.t[0][k] = __builtin_bit_cast(bf16x8, q);
+    }
+}
 
 #ifndef ZEST_PREFETCH
 #define ZEST_PREFETCH 3        // weight tiles kept in flight ahead of the MFMAs that consume them
@@ -328,10 +391,10 @@ struct OpArr {              // N k-tiles of one column block's operand; N = 0 al
 constexpr int kPrefetch = ZEST_PREFETCH;
 
 // What is fetched ahead for one row block: its bias initialisers and its first tiles.
-template <bool MOD>
+template <int NP>
 struct RowBlockPre {
     f32x4 bias[2], mbias[2];      // per row tile
-    bf16x8 win[kPrefetch];
+    bf16x8 win[kPrefetch][NP];
 };
 
 // One Linear: NJB row blocks (32 outputs = row tiles 0, 1) over the operand
@@ -341,18 +404,21 @@ struct RowBlockPre {
 //   MODE: 0 = produce k-tile jb of `out`, 1 = keep row tile 0 of row block 0 in `keep`
 //         (head / rgb: lane group g holds rows 4g .. 4g+3)
 // Unit order inside a row block: header, then per k-tile the row tiles 0, 1 (modulation k-tiles
-// first): four independent accumulators per 32 samples take turns.  The LDS reads are
-// software-pipelined by hand, in source order: every tile is requested kPrefetch tiles before
-// the MFMAs that use it, and the NEXT row block's header and first tiles are requested before
-// the CURRENT epilogue, whose VALU instructions cover their latency.
-template <int CB, int NJB, int NKA, int NKB, bool MOD, int NKF, bool RELU, int MODE, class Tiles>
+// first; a split tile is the unit pair hi, lo): independent accumulators take turns.  The LDS
+// reads are software-pipelined by hand, in source order: every tile is requested kPrefetch tiles
+// before the MFMAs that use it, and the NEXT row block's header and first tiles are requested
+// before the CURRENT epilogue, whose VALU instructions cover their latency.
+template <int EP, int CB, int NJB, int NKA, int NKB, bool MOD, int NKF, bool RELU, int MODE, class Tiles>
 __device__ __forceinline__ void engine_layer(const Tiles &tiles, int &unit, bool v2,
-                                             const OpArr<NKA> (&opa)[CB], const OpArr<NKB> (&opb)[CB],
-                                             const OpArr<NKF> (&opf)[CB], OpArr<8> (&out)[CB],
-                                             f32x4 (&keep)[CB]) {
+                                             const OpArr<NKA, ep_parts(EP)> (&opa)[CB],
+                                             const OpArr<NKB, ep_parts(EP)> (&opb)[CB],
+                                             const OpArr<NKF, ep_parts(EP)> (&opf)[CB],
+                                             OpArr<8, ep_parts(EP)> (&out)[CB], f32x4 (&keep)[CB]) {
+    constexpr int NP = ep_parts(EP);
+    constexpr bool X3 = EP == ZEST_PREC_F16X3;
     constexpr int NM = MOD ? 2 * NKF : 0, T = NM + 2 * (NKA + NKB);     // tiles per row block
     static_assert(T >= 1, "empty layer");
-    auto preload = [&](RowBlockPre<MOD> &p, int u0) {           // u0: the row block's header unit
+    auto preload = [&](RowBlockPre<NP> &p, int u0) {            // u0: the row block's header unit
 #pragma unroll
         for (int rt = 0; rt < 2; rt++) {
             p.bias[rt] = tiles.load_bias(u0, 0, rt);
@@ -360,43 +426,69 @@ __device__ __forceinline__ void engine_layer(const Tiles &tiles, int &unit, bool
         }
 #pragma unroll
         for (int k = 0; k < kPrefetch; k++)
-            if (k < T) p.win[k] = tiles.load(u0 + 1 + k);
+            if (k < T) {
+#pragma unroll
+                for (int pt = 0; pt < NP; pt++) p.win[k][pt] = tiles.load(u0 + 1 + NP * k + pt);
+            }
     };
-    RowBlockPre<MOD> pre;
+    RowBlockPre<NP> pre;
     preload(pre, unit);
 #pragma unroll
     for (int jb = 0; jb < NJB; jb++) {
         const int u0 = unit;
-        f32x4 acc[2][CB], macc[2][CB];
-        bf16x8 win[kPrefetch];
+        // acc: the hi*hi products (all products of the one-part types); corr: hi*lo + lo*hi, scaled 2^11
+        f32x4 acc[2][CB], macc[2][CB], corr[2][CB], mcorr[2][CB];
+        bf16x8 win[kPrefetch][NP];
 #pragma unroll
-        for (int k = 0; k < kPrefetch; k++) win[k] = pre.win[k];
+        for (int k = 0; k < kPrefetch; k++)
+#pragma unroll
+            for (int pt = 0; pt < NP; pt++) win[k][pt] = pre.win[k][pt];
 #pragma unroll
         for (int rt = 0; rt < 2; rt++)
 #pragma unroll
             for (int cb = 0; cb < CB; cb++) {
                 acc[rt][cb] = pre.bias[rt];
                 if (MOD) macc[rt][cb] = pre.mbias[rt];
+                if (X3) corr[rt][cb] = f32x4{0.f, 0.f, 0.f, 0.f}, mcorr[rt][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
         for (int k = 0; k < T; k++) {
-            const bf16x8 a = win[k % kPrefetch];
+            bf16x8 a[NP];
+#pragma unroll
+            for (int pt = 0; pt < NP; pt++) a[pt] = win[k % kPrefetch][pt];
             const int rt = k % 2, kt = (k < NM ? k : k - NM) / 2;          // compile-time after unrolling
 #pragma unroll
             for (int cb = 0; cb < CB; cb++) {
-                if (k < NM)
-                    macc[rt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, opf[cb].t[k < NM ? kt : 0], macc[rt][cb], 0, 0, 0);
-                else if (kt < NKA)
-                    acc[rt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, opa[cb].t[(k >= NM && kt < NKA) ? kt : 0], acc[rt][cb], 0, 0, 0);
-                else
-                    acc[rt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, opb[cb].t[(k >= NM && kt >= NKA) ? kt - NKA : 0], acc[rt][cb], 0, 0, 0);
+                // the operand k-tile this weight tile multiplies, part pt (every index is a
+                // compile-time constant after unrolling; the clamps keep dead branches in range)
+                auto opnd = [&](int pt) -> bf16x8 {
+                    if (k < NM) return opf[cb].t[pt][k < NM ? kt : 0];
+                    if (kt < NKA) return opa[cb].t[pt][(k >= NM && kt < NKA) ? kt : 0];
+                    return opb[cb].t[pt][(k >= NM && kt >= NKA) ? kt - NKA : 0];
+                };
+                if (k < NM) {
+                    macc[rt][cb] = mfma16<EP>(a[0], opnd(0), macc[rt][cb]);
+                    if constexpr (X3) {
+                        mcorr[rt][cb] = mfma16<EP>(a[0], opnd(NP - 1), mcorr[rt][cb]);
+                        mcorr[rt][cb] = mfma16<EP>(a[NP - 1], opnd(0), mcorr[rt][cb]);
+                    }
+                } else {
+                    acc[rt][cb] = mfma16<EP>(a[0], opnd(0), acc[rt][cb]);
+                    if constexpr (X3) {
+                        corr[rt][cb] = mfma16<EP>(a[0], opnd(NP - 1), corr[rt][cb]);
+                        corr[rt][cb] = mfma16<EP>(a[NP - 1], opnd(0), corr[rt][cb]);
+                    }
+                }
             }
-            if (k + kPrefetch < T) win[k % kPrefetch] = tiles.load(u0 + 1 + k + kPrefetch);
+            if (k + kPrefetch < T) {
+#pragma unroll
+                for (int pt = 0; pt < NP; pt++) win[k % kPrefetch][pt] = tiles.load(u0 + 1 + NP * (k + kPrefetch) + pt);
+            }
 #ifdef ZEST_SCHED_PIN
             __builtin_amdgcn_sched_barrier(0);      // keep the hand-made read-ahead distance
 #endif
         }
-        unit = u0 + 1 + T;
+        unit = u0 + 1 + NP * T;
         if (jb + 1 < NJB) preload(pre, unit);                   // in flight during the epilogue
 #pragma unroll
         for (int cb = 0; cb < CB; cb++) {
@@ -404,13 +496,16 @@ __device__ __forceinline__ void engine_layer(const Tiles &tiles, int &unit, bool
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 v[i] = acc[i >> 2][cb][i & 3];
-                if (MOD) v[i] = v2 ? v[i] + macc[i >> 2][cb][i & 3] : v[i] * macc[i >> 2][cb][i & 3];
-                if (RELU) v[i] = relu1(v[i]);
+                if (X3) v[i] = fmaf(corr[i >> 2][cb][i & 3], kLoUnscale, v[i]);
+                if (MOD) {
+                    float mv = macc[i >> 2][cb][i & 3];
+                    if (X3) mv = fmaf(mcorr[i >> 2][cb][i & 3], kLoUnscale, mv);
+                    v[i] = v2 ? v[i] + mv : v[i] * mv;
+                }
+                if (RELU) v[i] = relu1<EP>(v[i]);
             }
             if (MODE == 0) {
-                uint4 q = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]),
-                                     pack_bf16(v[6], v[7]));
-                out[cb].t[jb] = *reinterpret_cast<bf16x8 *>(&q);
+                store_tile<EP>(v, out[cb], jb);
             } else if (jb == 0) {
                 keep[cb] = f32x4{v[0], v[1], v[2], v[3]};
             }
@@ -418,50 +513,52 @@ __device__ __forceinline__ void engine_layer(const Tiles &tiles, int &unit, bool
     }
 }
 
-// The whole network for NB blocks of 32 samples (CB = 2 NB column blocks), reading the stream
-// from unit `unit` on (advanced to the end of the net's padded stream).  pts/feat: encoder
-// operands in plan position order, NU_* = their stream units per row block = 2 x k-tiles;
-// `views_fn(views)` builds the direction operand when it is first needed (op 10) so that it does
-// not occupy registers through the trunk.  Results per column block: head (lane group g: rows
-// 4g .. 4g+3 of the head tile; row 0 alpha, rows 1.. extra heads) and rgb (group 0: rows 0-2), raw.
-template <int NB, int NU_PTS, bool MOD, int NU_FEAT, class Tiles, class ViewsFn>
+// The whole network for CB column blocks of 16 samples, reading the stream from unit `unit` on
+// (advanced to the end of the net's padded stream).  pts/feat: encoder operands in plan position
+// order, NU_* = their logical stream tiles per row block = 2 x k-tiles; `views_fn(views)` builds
+// the direction operand when it is first needed (op 10) so that it does not occupy registers
+// through the trunk.  Results per column block: head (lane group g: rows 4g .. 4g+3 of the head
+// tile; row 0 alpha, rows 1.. extra heads) and rgb (group 0: rows 0-2), raw.
+template <int EP, int CB, int NU_PTS, bool MOD, int NU_FEAT, class Tiles, class ViewsFn>
 __device__ __forceinline__ void engine_forward(const Tiles &tiles, int &unit, bool v2,
-                                               const OpArr<NU_PTS / 2> (&pts)[2 * NB],
-                                               const OpArr<NU_FEAT / 2> (&feat)[2 * NB], ViewsFn views_fn,
-                                               f32x4 (&head)[2 * NB], f32x4 (&rgb)[2 * NB]) {
-    constexpr int CB = 2 * NB, KP = NU_PTS / 2, KF = NU_FEAT / 2;
+                                               const OpArr<NU_PTS / 2, ep_parts(EP)> (&pts)[CB],
+                                               const OpArr<NU_FEAT / 2, ep_parts(EP)> (&feat)[CB], ViewsFn views_fn,
+                                               f32x4 (&head)[CB], f32x4 (&rgb)[CB]) {
+    constexpr int KP = NU_PTS / 2, KF = NU_FEAT / 2, NP = ep_parts(EP);
     static_assert(NU_PTS % 2 == 0 && NU_FEAT % 2 == 0, "units per row block come in row-tile pairs");
-    OpArr<8> hA[CB], hB[CB];
-    OpArr<0> none[CB];
+    OpArr<8, NP> hA[CB], hB[CB];
+    OpArr<0, NP> none[CB];
     f32x4 unused[CB];
     const int unit0 = unit;
-    engine_layer<CB, 8, KP, 0, MOD, KF, true, 0>(tiles, unit, v2, pts, none, feat, hA, unused);
-    engine_layer<CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hA, none, feat, hB, unused);
-    engine_layer<CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hB, none, feat, hA, unused);
-    engine_layer<CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hA, none, feat, hB, unused);
-    engine_layer<CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hB, none, feat, hA, unused);
-    engine_layer<CB, 8, KP, 8, MOD, KF, true, 0>(tiles, unit, v2, pts, hA, feat, hB, unused);
-    engine_layer<CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hB, none, feat, hA, unused);
-    engine_layer<CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hA, none, feat, hB, unused);
+    engine_layer<EP, CB, 8, KP, 0, MOD, KF, true, 0>(tiles, unit, v2, pts, none, feat, hA, unused);
+    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hA, none, feat, hB, unused);
+    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hB, none, feat, hA, unused);
+    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hA, none, feat, hB, unused);
+    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hB, none, feat, hA, unused);
+    engine_layer<EP, CB, 8, KP, 8, MOD, KF, true, 0>(tiles, unit, v2, pts, hA, feat, hB, unused);
+    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hB, none, feat, hA, unused);
+    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hA, none, feat, hB, unused);
     // trunk output in hB
-    engine_layer<CB, 1, 8, 0, false, KF, false, 1>(tiles, unit, v2, hB, none, feat, hA, head);
-    engine_layer<CB, 8, 8, 0, false, KF, false, 0>(tiles, unit, v2, hB, none, feat, hA, unused);
-    OpArr<1> views[CB];
+    engine_layer<EP, CB, 1, 8, 0, false, KF, false, 1>(tiles, unit, v2, hB, none, feat, hA, head);
+    engine_layer<EP, CB, 8, 8, 0, false, KF, false, 0>(tiles, unit, v2, hB, none, feat, hA, unused);
+    OpArr<1, NP> views[CB];
     views_fn(views);
-    engine_layer<CB, 4, 8, 1, false, KF, true, 0>(tiles, unit, v2, hA, views, feat, hB, unused);
+    engine_layer<EP, CB, 4, 8, 1, false, KF, true, 0>(tiles, unit, v2, hA, views, feat, hB, unused);
     // rgb: 128 hidden features = first 4 k-tiles of hB
-    OpArr<4> h128[CB];
+    OpArr<4, NP> h128[CB];
 #pragma unroll
     for (int cb = 0; cb < CB; cb++)
 #pragma unroll
-        for (int k = 0; k < 4; k++) h128[cb].t[k] = hB[cb].t[k];
-    engine_layer<CB, 1, 4, 0, false, KF, false, 1>(tiles, unit, v2, h128, none, feat, hA, rgb);
-    tiles.finish(unit, unit0 + stream_units(NU_PTS, MOD ? NU_FEAT : 0));
-    unit = unit0 + stream_units(NU_PTS, MOD ? NU_FEAT : 0);
+        for (int pt = 0; pt < NP; pt++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) h128[cb].t[pt][k] = hB[cb].t[pt][k];
+    engine_layer<EP, CB, 1, 4, 0, false, KF, false, 1>(tiles, unit, v2, h128, none, feat, hA, rgb);
+    tiles.finish(unit, unit0 + stream_units(NU_PTS, MOD ? NU_FEAT : 0, NP));
+    unit = unit0 + stream_units(NU_PTS, MOD ? NU_FEAT : 0, NP);
 }
 
 // standalone launcher (mlp.hip -> zest_mlp_fwd)
-int mlp_bf16_launch(const MlpPlan &p, const void *tiles, const float *x, int M, float *out,
+int mlp_engine_launch(const MlpPlan &p, const void *tiles, const float *x, int M, float *out,
                     hipStream_t stream);
 
 }  // namespace zest

@@ -1,6 +1,7 @@
-// Standalone bf16 MLP forward (zest_mlp_fwd, ZEST_PREC_BF16): x [M,C_in] fp32 in HBM ->
-// operand registers -> engine -> out [M,C_out].  Backs MVSNeRF.forward in bf16 mode and the
-// MFMA-utilisation measurement of the MLP alone.  Same structure as the fused renderer: 8 waves
+// Standalone MLP forward on the register engine (zest_mlp_fwd, ZEST_PREC_BF16 / _F16 / _F16X3):
+// x [M,C_in] fp32 in HBM -> operand registers -> engine -> out [M,C_out].  Backs MVSNeRF.forward
+// in the 16-bit modes, the fp32-class per-op path (split fp16) and the MFMA-utilisation
+// measurement of the MLP alone.  Same structure as the fused renderer: 8 waves
 // per workgroup share the weight stream through the LDS ring (LDS-DMA), each wave carries 32
 // rows through the network in registers; only the operand source (rows of x instead of the
 // in-kernel encoders) and the sink (raw network outputs instead of compositing) differ.
@@ -16,8 +17,9 @@ namespace zest {
 //                   = [C + 4C (m / C) + m % C] + [(g >> 1) 2C + (g & 1) C];   m = (L/2) C: column g (< C)
 //   feature operand: quad q = 8 kt + 2 g + (e >> 2), channel c = e & 3:
 //     q = 0, 2: volume columns c, 4 + c;  q = 1, 3: columns 8 + c, 12 + c;  q >= 4: column 4 q + c
-template <int C, int L, int NK>
-__device__ __forceinline__ void load_pe_operand(const float *__restrict__ xrow, bool valid, int grp, OpArr<NK> &op) {
+template <int EP, int C, int L, int NK>
+__device__ __forceinline__ void load_pe_operand(const float *__restrict__ xrow, bool valid, int grp,
+                                                OpArr<NK, ep_parts(EP)> &op) {
     const float *xg = xrow + (grp >> 1) * 2 * C + (grp & 1) * C;
     const float raw = (valid && grp < C) ? xrow[grp < C ? grp : 0] : 0.0f;
 #pragma unroll
@@ -31,13 +33,13 @@ __device__ __forceinline__ void load_pe_operand(const float *__restrict__ xrow, 
             else
                 v[e] = m == (L / 2) * C ? raw : 0.0f;
         }
-        uint4 a = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
-        op.t[t] = *reinterpret_cast<bf16x8 *>(&a);
+        store_tile<EP>(v, op, t);
     }
 }
 
-template <int NK>
-__device__ __forceinline__ void load_feat_operand(const float *__restrict__ xf, int F, bool valid, int grp, OpArr<NK> &op) {
+template <int EP, int NK>
+__device__ __forceinline__ void load_feat_operand(const float *__restrict__ xf, int F, bool valid, int grp,
+                                                  OpArr<NK, ep_parts(EP)> &op) {
 #pragma unroll
     for (int t = 0; t < NK; t++) {
         // first columns of this lane's two quads
@@ -53,19 +55,20 @@ __device__ __forceinline__ void load_feat_operand(const float *__restrict__ xf, 
         float v[8];
 #pragma unroll
         for (int c = 0; c < 4; c++) v[c] = va ? pa[c] : 0.0f, v[4 + c] = vb ? pb[c] : 0.0f;
-        uint4 a = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
-        op.t[t] = *reinterpret_cast<bf16x8 *>(&a);
+        store_tile<EP>(v, op, t);
     }
 }
 
-// A wave runs NB blocks of 32 rows = 2 NB column blocks of 16 (lane: column l & 15, group l >> 4).
+// A wave runs CB column blocks of 16 rows (lane: column l & 15, group l >> 4): two, or one where
+// every operand is a register pair (split fp16).
 constexpr int kMlpWaves = 8;
+constexpr int mlp_cb(int EP) { return EP == ZEST_PREC_F16X3 ? 1 : 2; }
 
-template <int NB, int NT_PTS, bool MOD, int NT_FEAT>
-__global__ __launch_bounds__(kMlpWaves * 64, kMlpWaves / 4) void mlp_bf16_kernel(
+template <int EP, int NT_PTS, bool MOD, int NT_FEAT>
+__global__ __launch_bounds__(kMlpWaves * 64, kMlpWaves / 4) void mlp_engine_kernel(
     const uint4 *__restrict__ tiles_g, const float *__restrict__ x, int M, int P, int F, int C_in, int C_out, int head, int v2,
     float *__restrict__ out) {
-    constexpr int CB = 2 * NB, UNITS = stream_units(NT_PTS, MOD ? NT_FEAT : 0);
+    constexpr int NP = ep_parts(EP), CB = mlp_cb(EP), UNITS = stream_units(NT_PTS, MOD ? NT_FEAT : 0, NP);
     using Ring = RingTiles<kMlpWaves, UNITS, 0>;
     __shared__ __attribute__((aligned(16))) char lds[kRingUnits * 1024 + 2 * kSlots * 4];
 #ifdef ZEST_RING_FLAGS
@@ -85,32 +88,32 @@ __global__ __launch_bounds__(kMlpWaves * 64, kMlpWaves / 4) void mlp_bf16_kernel
     };
     tiles.init_addr();
     tiles.prologue();
-    const int n_blocks = (M + 32 * NB - 1) / (32 * NB), n_pass = (n_blocks + kMlpWaves - 1) / kMlpWaves;
+    const int n_blocks = (M + 16 * CB - 1) / (16 * CB), n_pass = (n_blocks + kMlpWaves - 1) / kMlpWaves;
     for (int pass = blockIdx.x; pass < n_pass; pass += gridDim.x) {
         // every wave walks the stream in step, also one whose rows lie past M (its loads are
         // clamped and its stores masked)
-        const long long m_base = ((long long)pass * kMlpWaves + wave) * (32 * NB);
-        OpArr<NT_PTS / 2> pts[CB];
-        OpArr<NT_FEAT / 2> feat[CB];
+        const long long m_base = ((long long)pass * kMlpWaves + wave) * (16 * CB);
+        OpArr<NT_PTS / 2, NP> pts[CB];
+        OpArr<NT_FEAT / 2, NP> feat[CB];
 #pragma unroll
         for (int cb = 0; cb < CB; cb++) {
             const long long m = m_base + 16 * cb + col;
             const bool valid = m < M;
             const float *xrow = x + (size_t)(valid ? m : 0) * C_in;
-            load_pe_operand<NT_PTS == 4 ? 3 : 4, 10, NT_PTS / 2>(xrow, valid, grp, pts[cb]);
-            if (MOD) load_feat_operand<NT_FEAT / 2>(xrow + P, F, valid, grp, feat[cb]);
+            load_pe_operand<EP, NT_PTS == 4 ? 3 : 4, 10, NT_PTS / 2>(xrow, valid, grp, pts[cb]);
+            if (MOD) load_feat_operand<EP, NT_FEAT / 2>(xrow + P, F, valid, grp, feat[cb]);
         }
-        auto views_fn = [&](OpArr<1> (&views)[CB]) {
+        auto views_fn = [&](OpArr<1, NP> (&views)[CB]) {
 #pragma unroll
             for (int cb = 0; cb < CB; cb++) {
                 const long long m = m_base + 16 * cb + col;
                 const bool valid = m < M;
-                load_pe_operand<3, 4, 1>(x + (size_t)(valid ? m : 0) * C_in + P + F, valid, grp, views[cb]);
+                load_pe_operand<EP, 3, 4, 1>(x + (size_t)(valid ? m : 0) * C_in + P + F, valid, grp, views[cb]);
             }
         };
         f32x4 headt[CB], rgbt[CB];
         int unit = 0;
-        engine_forward<NB, NT_PTS, MOD, NT_FEAT>(tiles, unit, v2 != 0, pts, feat, views_fn, headt, rgbt);
+        engine_forward<EP, CB, NT_PTS, MOD, NT_FEAT>(tiles, unit, v2 != 0, pts, feat, views_fn, headt, rgbt);
 #pragma unroll
         for (int cb = 0; cb < CB; cb++) {
             const long long m = m_base + 16 * cb + col;
@@ -137,12 +140,12 @@ __global__ __launch_bounds__(kMlpWaves * 64, kMlpWaves / 4) void mlp_bf16_kernel
     tiles.drain();
 }
 
-template <int NB, int NT_PTS, bool MOD, int NT_FEAT>
+template <int EP, int NT_PTS, bool MOD, int NT_FEAT>
 static int launch_one(const MlpPlan &p, const void *tiles, const float *x, int M,
                       float *out, hipStream_t stream) {
-    if (p.n_tiles != stream_units(NT_PTS, MOD ? NT_FEAT : 0)) {
-        zest_set_error("zest_mlp_fwd(bf16): plan has %d stream units, kernel expects %d", p.n_tiles,
-                       stream_units(NT_PTS, MOD ? NT_FEAT : 0));
+    constexpr int units = stream_units(NT_PTS, MOD ? NT_FEAT : 0, ep_parts(EP));
+    if (p.n_tiles != units) {
+        zest_set_error("zest_mlp_fwd(engine): plan has %d stream units, kernel expects %d", p.n_tiles, units);
         return (int)hipErrorInvalidValue;
     }
     const zest_mlp_desc &d = p.desc;
@@ -153,28 +156,39 @@ static int launch_one(const MlpPlan &p, const void *tiles, const float *x, int M
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         cus = 256;
-    const int n_pass = zest_div_up(zest_div_up(M, 32 * NB), kMlpWaves);
+    const int n_pass = zest_div_up(zest_div_up(M, 16 * mlp_cb(EP)), kMlpWaves);
     const int blocks = n_pass < cus ? n_pass : cus;             // one workgroup per CU (128 KiB ring)
-    hipLaunchKernelGGL((mlp_bf16_kernel<NB, NT_PTS, MOD, NT_FEAT>), dim3(blocks), dim3(kMlpWaves * 64), 0, stream,
+    hipLaunchKernelGGL((mlp_engine_kernel<EP, NT_PTS, MOD, NT_FEAT>), dim3(blocks), dim3(kMlpWaves * 64), 0, stream,
                        (const uint4 *)tiles, x, M, d.in_ch_pts, F, C_in, C_out, d.head,
                        d.net_type == 2 ? 1 : 0, out);
-    ZEST_RETURN_LAUNCH("zest_mlp_fwd(bf16)");
+    ZEST_RETURN_LAUNCH("zest_mlp_fwd(engine)");
 }
 
-int mlp_bf16_launch(const MlpPlan &p, const void *tiles, const float *x, int M, float *out,
-                    hipStream_t stream) {
+template <int EP>
+static int launch_prec(const MlpPlan &p, const void *tiles, const float *x, int M, float *out, hipStream_t stream) {
     const bool mod = p.desc.use_feat != 0;
     const int key = p.nt_pts * 10 + (mod ? p.nt_feat : 0);
     switch (key) {
-        case 40: return launch_one<1, 4, false, 0>(p, tiles, x, M, out, stream);
-        case 42: return launch_one<1, 4, true, 2>(p, tiles, x, M, out, stream);
-        case 44: return launch_one<1, 4, true, 4>(p, tiles, x, M, out, stream);
-        case 60: return launch_one<1, 6, false, 0>(p, tiles, x, M, out, stream);
-        case 62: return launch_one<1, 6, true, 2>(p, tiles, x, M, out, stream);
-        case 64: return launch_one<1, 6, true, 4>(p, tiles, x, M, out, stream);
+        case 40: return launch_one<EP, 4, false, 0>(p, tiles, x, M, out, stream);
+        case 42: return launch_one<EP, 4, true, 2>(p, tiles, x, M, out, stream);
+        case 44: return launch_one<EP, 4, true, 4>(p, tiles, x, M, out, stream);
+        case 60: return launch_one<EP, 6, false, 0>(p, tiles, x, M, out, stream);
+        case 62: return launch_one<EP, 6, true, 2>(p, tiles, x, M, out, stream);
+        case 64: return launch_one<EP, 6, true, 4>(p, tiles, x, M, out, stream);
     }
-    zest_set_error("zest_mlp_fwd(bf16): no kernel for %d point units / %d feature units per row "
+    zest_set_error("zest_mlp_fwd(engine): no kernel for %d point units / %d feature units per row "
                    "block (supported: 1..14 source views)", p.nt_pts, mod ? p.nt_feat : 0);
+    return (int)hipErrorInvalidValue;
+}
+
+int mlp_engine_launch(const MlpPlan &p, const void *tiles, const float *x, int M, float *out,
+                      hipStream_t stream) {
+    switch (p.precision) {
+        case ZEST_PREC_BF16: return launch_prec<ZEST_PREC_BF16>(p, tiles, x, M, out, stream);
+        case ZEST_PREC_F16: return launch_prec<ZEST_PREC_F16>(p, tiles, x, M, out, stream);
+        case ZEST_PREC_F16X3: return launch_prec<ZEST_PREC_F16X3>(p, tiles, x, M, out, stream);
+    }
+    zest_set_error("zest_mlp_fwd(engine): precision %d is not an engine operand type", p.precision);
     return (int)hipErrorInvalidValue;
 }
 

@@ -35,6 +35,11 @@
 //     stream is self-contained and can be fed through an LDS ring; it is padded with zero
 //     units to a multiple of kStreamAlign units so a ring of that many units keeps a fixed
 //     phase from one pass to the next.
+// Operand types of the engine (include/zest_render.h): bf16, fp16 (same stream layout, 2-byte
+// elements) and the split fp16 pair ZEST_PREC_F16X3: there every weight tile is TWO consecutive
+// units, hi = fp16(w) and lo = fp16((w - hi) * 2^11) (MlpPlan::parts = 2; the tile counts nt_*
+// stay logical, unit counts double), and the kernel forms a product as
+// hi*hi + 2^-11 (hi*lo + lo*hi).
 #pragma once
 #include <stdint.h>
 #include <vector>
@@ -78,6 +83,7 @@ struct MlpPlan {
     int ns_pts, ns_feat, ns_views; // padded slot counts of the encoder operands
     int nt_pts, nt_feat, nt_views, nt_h, nt_h128;
     int headers;                   // 1: ORDER_ACC stream with inline header units
+    int parts;                     // stream units per weight tile: 1, or 2 (hi, lo) for ZEST_PREC_F16X3
     int n_tiles, n_bias_blocks;    // n_tiles includes headers and tail padding
     size_t bias_bytes, bytes;      // bias area (padded to 1 KiB) and total
     OpPlan op[kNumOps];
@@ -89,7 +95,13 @@ struct MlpPlan {
     std::vector<uint32_t> tile_src, bias_src;
     // headers mode: per unit, 64 fp32 sources of the header payload (only header units are set)
     std::vector<uint32_t> hdr_src;
+    // per unit: 0 = plain / hi tile, 1 = lo tile of a split pair (header and padding units: 0)
+    std::vector<uint8_t> unit_part;
 };
+
+inline bool prec_is_engine(int precision) {     // the register engine's operand types (ORDER_ACC)
+    return precision == ZEST_PREC_BF16 || precision == ZEST_PREC_F16 || precision == ZEST_PREC_F16X3;
+}
 
 // Builds the plan; returns false (with *err set) for shapes the kernels do not cover.
 // with_tables = false skips the packer's gather tables (cheap: launch-time shape queries).

@@ -72,12 +72,14 @@ struct RowSrc { int param, row; };       // param < 0: zero row
 
 bool build_plan(const zest_mlp_desc &d, int precision, int order, MlpPlan *P, const char **err,
                 bool with_tables) {
-    static const char *e_prec = "precision must be ZEST_PREC_F32 or ZEST_PREC_BF16";
+    static const char *e_prec = "precision must be ZEST_PREC_F32, _BF16, _F16 or _F16X3";
     static const char *e_pts = "in_ch_pts must be 63 (xyz, L=10) or 84 (xyzt, L=10)";
     static const char *e_views = "in_ch_views must be 27 (L=4)";
     static const char *e_feat = "in_ch_feat must be 8 + 4V with 1 <= V <= 16 when use_feat is set";
     static const char *e_head = "bad head / net_type combination";
-    if (precision != ZEST_PREC_F32 && precision != ZEST_PREC_BF16) return *err = e_prec, false;
+    if (precision != ZEST_PREC_F32 && !prec_is_engine(precision)) return *err = e_prec, false;
+    if ((order == ORDER_ACC) != prec_is_engine(precision))
+        return *err = "ORDER_ACC goes with the engine precisions, ORDER_NATURAL with fp32", false;
     if (d.in_ch_pts != 63 && d.in_ch_pts != 84) return *err = e_pts, false;
     if (d.in_ch_views != 27) return *err = e_views, false;
     const int F = d.use_feat ? d.in_ch_feat : 0;
@@ -88,7 +90,8 @@ bool build_plan(const zest_mlp_desc &d, int precision, int order, MlpPlan *P, co
 
     MlpPlan &p = *P;
     p.desc = d, p.precision = precision, p.order = order;
-    p.spt = precision == ZEST_PREC_BF16 ? 8 : 4;
+    p.spt = prec_is_engine(precision) ? 8 : 4;
+    p.parts = precision == ZEST_PREC_F16X3 ? 2 : 1;
     const int spt = p.spt, C = d.in_ch_pts == 63 ? 3 : 4, V = d.use_feat ? (F - 8) / 4 : 0;
     if (order == ORDER_ACC) {
         // "slots" are positions here and a tile (16 rows x 32 positions) covers half a k-tile's
@@ -124,8 +127,8 @@ bool build_plan(const zest_mlp_desc &d, int precision, int order, MlpPlan *P, co
         if (o == 8) op.njb = 1;
         if (o == 10) op.njb = 4, op.relu = 1, op.nseg = 2, op.seg[1] = {SEG_VIEWS, p.nt_views};
         if (o == 11) op.njb = 1, op.seg[0] = {SEG_H, p.nt_h128};
-        op.tiles_per_jb = (op.mod ? p.nt_feat : 0) + p.headers;
-        for (int s = 0; s < op.nseg; s++) op.tiles_per_jb += op.seg[s].ntiles;
+        op.tiles_per_jb = (op.mod ? p.nt_feat : 0) * p.parts + p.headers;
+        for (int s = 0; s < op.nseg; s++) op.tiles_per_jb += op.seg[s].ntiles * p.parts;
         op.tile_base = tile, op.bias_block = bblk;
         tile += op.njb * op.tiles_per_jb, bblk += op.njb;
     }
@@ -142,6 +145,7 @@ bool build_plan(const zest_mlp_desc &d, int precision, int order, MlpPlan *P, co
     p.tile_src.assign((size_t)tile * 64 * spt, ZERO);
     p.bias_src.assign(p.bias_bytes / 4, ZERO);
     p.hdr_src.assign(p.headers ? (size_t)tile * 64 : 0, ZERO);   // 64 floats at the head of a header unit
+    p.unit_part.assign((size_t)tile, 0);
 
     auto row_src = [&](int o, int row) -> RowSrc {
         if (o < 8) return {ZEST_P_PTS0 + o, row};
@@ -157,7 +161,9 @@ bool build_plan(const zest_mlp_desc &d, int precision, int order, MlpPlan *P, co
     };
     auto emit_tiles = [&](int &t, int param_of_rows_op, int jb, const SegPlan &sg, int col0,
                           bool is_mod) {
-        for (int k = 0; k < sg.ntiles; k++, t++)
+        for (int k = 0; k < sg.ntiles; k++)
+          for (int part = 0; part < p.parts; part++, t++) {      // split pair: hi unit, then lo unit
+            p.unit_part[t] = (uint8_t)part;
             for (int l = 0; l < 64; l++)
                 for (int e = 0; e < spt; e++) {
                     int slot, half, row, feat;
@@ -185,6 +191,7 @@ bool build_plan(const zest_mlp_desc &d, int precision, int order, MlpPlan *P, co
                     p.tile_src[((size_t)t * 64 + l) * spt + e] =
                         ((uint32_t)rs.param << 24) | (uint32_t)(rs.row * ld[rs.param] + col0 + feat);
                 }
+          }
     };
     auto emit_bias_to = [&](std::vector<uint32_t> &dst, size_t at, int o, int jb, bool is_mod) {
         for (int h = 0; h < 2; h++)

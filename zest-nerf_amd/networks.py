@@ -8,9 +8,11 @@ match the reference (networks.py:29-353) so its checkpoints load with
 (include/zest_render.h).  There is no PyTorch implementation of the forward pass here:
 without libzest_hip.so, or on CPU tensors, calls raise.
 
-Precision: fp32 (exact-product MFMA, parity mode) unless the hyper-parameters say
-`precision=16` (the reference's --precision flag, opt.py:69) or ZEST_PRECISION=bf16 is
-set, which selects the bf16 MFMA engine.
+Precision (resolve_precision): the reference's `--precision 32` (opt.py:69, the default) runs the
+MLP on exact-product fp32 MFMA per operator and, in the fused single-launch renderer, on
+split-fp16 operand pairs (fp32-class results at the fp16 matrix rate); `--precision 16` selects
+16-bit operands with fp32 accumulation - bf16 by default, fp16 with `args.zest_dtype16 = "f16"`.
+ZEST_PRECISION = fp32 | f16x3 | bf16 | f16 overrides both.
 """
 import os
 
@@ -24,15 +26,25 @@ __all__ = ["Embedding", "Renderer", "Renderer_linear", "MVSNeRF", "resolve_preci
            "MVSNeRF_G", "DyMVSNeRF_G"]
 
 
+_PREC_BY_NAME = {"bf16": zest_hip.PREC_BF16, "16": zest_hip.PREC_BF16,
+                 "f16": zest_hip.PREC_F16, "fp16": zest_hip.PREC_F16, "half": zest_hip.PREC_F16,
+                 "f16x3": zest_hip.PREC_F16X3, "fp16x3": zest_hip.PREC_F16X3, "x3": zest_hip.PREC_F16X3,
+                 "fp32": zest_hip.PREC_F32, "f32": zest_hip.PREC_F32, "32": zest_hip.PREC_F32}
+
+
 def resolve_precision(args=None):
-    """-> zest_hip.PREC_F32 | PREC_BF16 from ZEST_PRECISION or args.precision (16|32)."""
+    """-> zest_hip.PREC_* from ZEST_PRECISION, else args.precision (16 | 32) and, for 16,
+    args.zest_dtype16 ("bf16" default | "f16")."""
     env = os.environ.get("ZEST_PRECISION", "").lower()
-    if env in ("bf16", "16"):
-        return zest_hip.PREC_BF16
-    if env in ("fp32", "f32", "32"):
-        return zest_hip.PREC_F32
+    if env:
+        if env not in _PREC_BY_NAME:
+            raise ValueError("ZEST_PRECISION=%r: expected one of %s" % (env, sorted(_PREC_BY_NAME)))
+        return _PREC_BY_NAME[env]
     if args is not None and int(getattr(args, "precision", 32) or 32) == 16:
-        return zest_hip.PREC_BF16
+        name = str(getattr(args, "zest_dtype16", "bf16")).lower()
+        if name not in ("bf16", "f16", "fp16"):
+            raise ValueError("args.zest_dtype16=%r: expected 'bf16' or 'f16'" % (name,))
+        return _PREC_BY_NAME[name]
     return zest_hip.PREC_F32
 
 

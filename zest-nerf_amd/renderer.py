@@ -14,7 +14,8 @@ Two execution plans:
   * fused     - one launch, per-ray maps only (zest_render_fused_fwd); chosen for
                 inference-shaped calls when `args.zest_maps_only` is set (the whole-image
                 loops in the generators set it: they read 2 / 7 per-ray maps only,
-                reference networks.py:697-704, train.py:898-899).
+                reference networks.py:697-704, train.py:898-899).  Operand type by
+                networks.resolve_precision: bf16 / fp16, or split-fp16 pairs in fp32 mode.
 """
 import torch
 
@@ -152,7 +153,7 @@ def _net(network_fn, what):
     return network_fn
 
 
-def _render_maps_fused(rays_ndc, ndc, pts, z, dirs, net_s, network_fn_dy, scene_flow, vol_s, vol_d,
+def _render_maps_fused(prec, rays_ndc, ndc, pts, z, dirs, net_s, network_fn_dy, scene_flow, vol_s, vol_d,
                        imgs, nb_imgs, cam, nb_cam, embedding_xyzt, embedding_dir, ref_frame_idx,
                        white_bkgd, raw_noise_std):
     """Per-ray maps only, one kernel launch (zest_render_fused_fwd).  Returns the per-ray keys
@@ -166,11 +167,11 @@ def _render_maps_fused(rays_ndc, ndc, pts, z, dirs, net_s, network_fn_dy, scene_
         net_d = _net(network_fn_dy, "network_fn_dy")
         _check_embedders(embedding_xyzt, embedding_dir, 4)
         vd = _Views(vol_d, nb_imgs, nb_cam)
-        desc_d, packed_d = net_d.desc(), net_d.packed(zest_hip.PREC_BF16)
+        desc_d, packed_d = net_d.desc(), net_d.packed(prec)
         views_d = zest_hip.make_view_set(vd.vol_cl, vd.imgs_cl, vd.w2cs, vd.intr)
-    out = zest_hip.render_fused(ndc, pts, z, dirs, net_s.desc(), net_s.packed(zest_hip.PREC_BF16),
+    out = zest_hip.render_fused(ndc, pts, z, dirs, net_s.desc(), net_s.packed(prec),
                                 views_s, desc_d, packed_d, views_d,
-                                ref_frame_idx if scene_flow else 0.0, white_bkgd)
+                                ref_frame_idx if scene_flow else 0.0, white_bkgd, precision=prec)
     ret = {'rgb_map': out[None, :, 0:3], 'depth_map': out[None, :, 3], 'acc_map': out[None, :, 4],
            'zest_packed_maps': out}
     if scene_flow:
@@ -218,8 +219,12 @@ def rendering(args, rays_pts, rays_ndc, depth_candidates, rays_dir,
     if train:
         import zest_autograd as za
 
-    if prec == zest_hip.PREC_BF16 and getattr(args, "zest_maps_only", False) and (val or not scene_flow):
-        return _render_maps_fused(rays_ndc, ndc, pts, z, dirs, net_s, network_fn_dy, scene_flow,
+    # Fused single-launch plan: inference-shaped calls that read per-ray maps only.  fp32 mode runs
+    # it on split-fp16 operand pairs (fp32-class results); a call that records a gradient takes the
+    # complete plan below, whose stages have backward kernels.
+    if getattr(args, "zest_maps_only", False) and (val or not scene_flow) and not train:
+        fused_prec = zest_hip.PREC_F16X3 if prec == zest_hip.PREC_F32 else prec
+        return _render_maps_fused(fused_prec, rays_ndc, ndc, pts, z, dirs, net_s, network_fn_dy, scene_flow,
                                   volume_feature_static, volume_feature_dynamic, imgs,
                                   neighbour_frames, im_cam_mat, nb_cam_mat, embedding_xyzt,
                                   embedding_dir, ref_frame_idx, white_bkgd, raw_noise_std)

@@ -15,7 +15,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ZEST_HIP_LIB selects an experiment build (build_hip.py --tag); default is the product library
 LIB_PATH = os.environ.get("ZEST_HIP_LIB") or os.path.join(_HERE, "libzest_hip.so")
 
-PREC_F32, PREC_BF16 = 0, 1
+# arithmetic of the MLP contraction (include/zest_render.h ZEST_PREC_*): exact-product fp32 MFMA;
+# bf16 / fp16 operands; split-fp16 pairs (fp32-class results on the fp16 matrix pipe)
+PREC_F32, PREC_BF16, PREC_F16, PREC_F16X3 = 0, 1, 2, 3
+ENGINE_PRECISIONS = (PREC_BF16, PREC_F16, PREC_F16X3)
+PREC_NAMES = {PREC_F32: "f32", PREC_BF16: "bf16", PREC_F16: "f16", PREC_F16X3: "f16x3"}
 HEAD_NONE, HEAD_BLEND, HEAD_DYNAMIC = 0, 1, 2
 P_COUNT = 15
 
@@ -83,6 +87,7 @@ _SIGS = {
                                    C.POINTER(ViewSet), C.POINTER(MlpDesc), _vp, C.POINTER(ViewSet),
                                    _f, _i, _i, _vp, _vp, _vp]),
     "zest_render_fused_workspace": (_sz, [_i, _i]),
+    "zest_render_fused_set_passes": (_i, [_i]),
 }
 
 _lib = None
@@ -104,8 +109,9 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)           # AttributeError if the header and library disagree
             fn.restype, fn.argtypes = res, args
-        if L.zest_abi_version() != 1:
-            raise RuntimeError("libzest_hip.so ABI %d != 1" % L.zest_abi_version())
+        if L.zest_abi_version() != 2:
+            raise RuntimeError("libzest_hip.so ABI %d != 2: rebuild it (python zest-nerf_amd/build_hip.py)"
+                               % L.zest_abi_version())
         _lib = L
     return _lib
 
@@ -524,10 +530,20 @@ def make_view_set(vol_cl=None, imgs_cl=None, w2cs=None, intrinsics=None):
     return vs
 
 
+def set_fused_passes(shape):
+    """None / "auto": pass shape chosen per launch; "dense" | "aligned": forced (tests, measurements)."""
+    _check(lib().zest_render_fused_set_passes({None: 0, "auto": 0, "dense": 1, "aligned": 2}[shape]),
+           "zest_render_fused_set_passes")
+
+
 def render_fused(ndc, pts, z, rays_dir, desc_s, packed_s, views_s, desc_d=None, packed_d=None,
-                 views_d=None, frame_idx=0.0, white_bkgd=False, out=None, workspace=None):
-    """One launch for the inference path.  ndc, pts [R,S,3]; z [R,S]; rays_dir [R,3].
+                 views_d=None, frame_idx=0.0, white_bkgd=False, out=None, workspace=None,
+                 precision=PREC_BF16):
+    """One launch for the inference path.  ndc, pts [R,S,3]; z [R,S]; rays_dir [R,3]; the packed
+    weights must have been packed for `precision` (one of ENGINE_PRECISIONS).
     Returns out [R,16] (column layout: include/zest_render.h)."""
+    if precision not in ENGINE_PRECISIONS:
+        raise RuntimeError("zest_hip.render_fused: precision %r is not an engine operand type" % (precision,))
     ndc, pts, z, rays_dir = _dev(ndc, "ndc"), _dev(pts, "pts"), _dev(z, "z"), _dev(rays_dir, "rays_dir")
     R, S = z.shape
     if out is None:
@@ -539,6 +555,6 @@ def render_fused(ndc, pts, z, rays_dir, desc_s, packed_s, views_s, desc_d=None, 
         _ptr(ndc), _ptr(pts), _ptr(z), _ptr(rays_dir), R, S, C.byref(desc_s), _ptr(packed_s),
         C.byref(views_s) if views_s is not None else None,
         C.byref(desc_d) if desc_d is not None else None, _ptr(packed_d),
-        C.byref(views_d) if views_d is not None else None, float(frame_idx), PREC_BF16,
+        C.byref(views_d) if views_d is not None else None, float(frame_idx), int(precision),
         int(bool(white_bkgd)), _ptr(workspace), _ptr(out), _stream(z)), "zest_render_fused_fwd")
     return out

@@ -62,7 +62,7 @@ WORKLOADS = {
 def build_workload(name, seed, device, rays=None, lively=True):
     """lively: He-scale weights (O(1) activations; colours saturate) as in the bench; False: nn.Linear's
     default scale (colours near 0.5, semi-transparent rays), the sensitive case for the PSNR check."""
-    import networks
+    import zest_networks as networks
     import zest_synth as zs
     w = dict(WORKLOADS[name])
     R = rays or w["R"]
@@ -98,7 +98,7 @@ def build_workload(name, seed, device, rays=None, lively=True):
 
 
 def render_step(d):
-    import renderer
+    import zest_renderer as renderer
     return renderer.rendering(
         d.args, d.t["rays_pts"], d.t["rays_ndc"], d.t["depth_candidates"], d.t["rays_dir"],
         volume_feature_static=d.vol_s, volume_feature_dynamic=d.vol_d, imgs=d.imgs,

@@ -35,9 +35,9 @@ def _shard_worker(rank, world, port, q):
             sys.path.insert(0, p)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    import networks
-    import renderer
-    import utils
+    import zest_networks as networks
+    import zest_renderer as renderer
+    import zest_utils as utils
     H, W, chunk = 6, 9, 8                                  # 54 pixels: 7 chunks, the last one short
     calls = []
 
@@ -112,7 +112,7 @@ def _batch(seed, H=32, W=32, V=3, V_dy=3):     # MVSNet's regulariser takes 3 vi
 
 
 def _generator(args):
-    import networks
+    import zest_networks as networks
     import golden_cases as gc
     torch.manual_seed(1)
     mk = lambda P, F, static: networks.MVSNeRF(D=8, W=256, input_ch_pts=P, output_ch=4, input_ch_views=gc.PE_DIR,

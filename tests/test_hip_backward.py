@@ -66,7 +66,7 @@ def test_blend_backward(hip):
 
 @pytest.mark.parametrize("case", [c for c in gc.CASES if gc.CASES[c]["kind"] == "mlp"])
 def test_mlp_train_forward_backward(hip, case):
-    import networks
+    import zest_networks as networks
     zh, inp, desc, _ = _mlp_setup(case)
     net = networks.MVSNeRF(D=8, W=256, input_ch_pts=inp["P"], input_ch_views=27, input_ch_feat=inp["Fd"],
                            net_type=inp["net_type"], sceneflow=inp["sceneflow"], static=inp["static"],
@@ -96,7 +96,7 @@ def test_mlp_train_forward_backward(hip, case):
 
 
 def test_encode_backward(hip):
-    import renderer
+    import zest_renderer as renderer
     import zest_autograd as za
     sc = gc.render_inputs(77, R=16, S=12)
     ndc = G(sc["rays_ndc"])[0].requires_grad_(True)
@@ -122,8 +122,8 @@ def test_encode_backward(hip):
 def test_rendering_training_gradients(hip, case):
     """Whole train-mode rendering(): loss over every differentiable output, gradients of both
     MLPs' parameters and both encoding volumes."""
-    import networks
-    import renderer
+    import zest_networks as networks
+    import zest_renderer as renderer
     from types import SimpleNamespace
     c, sc = gc.CASES[case], gc.build(case)
     sf = sc["scene_flow"]

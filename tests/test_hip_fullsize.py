@@ -57,7 +57,7 @@ def test_fused_equals_per_op_path_at_full_size(hip, name):
 def test_fused_ray_permutation_and_sharding_invariance(hip):
     """Rays are independent units: permuting the batch permutes the maps bit for bit, and rendering
     two halves separately gives the rows of the full render (the multi-GPU sharding argument)."""
-    import renderer
+    import zest_renderer as renderer
     d = _workload("nsff_zest_val_1024x128", rays=96)
     full = _maps(d)["zest_packed_maps"].clone()
     perm = torch.randperm(96, generator=torch.Generator().manual_seed(3)).cuda()
@@ -130,7 +130,7 @@ def test_other_baseline_configs_against_the_oracle(hip, name, rays):
     subset for the CPU oracle): fp32 per-op path within 1e-4 / 1e-3 of the oracle, fused bf16
     renderer within the bf16 tolerance and the 0.05 dB PSNR criterion."""
     import bench
-    import renderer
+    import zest_renderer as renderer
     d = _workload(name, rays=rays)
     with torch.no_grad():
         fused = bench.render_step(d)

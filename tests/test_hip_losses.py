@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 
 def test_distortion_loss_matches_reference(hip):
-    import losses
+    import zest_losses as losses
     inp, gold = gc.build("loss_side"), gc.load_golden("loss_side")
     w = G(inp["weights"]).requires_grad_(True)
     loss = losses.distortion_loss(w, G(inp["t_vals"]))
@@ -38,7 +38,7 @@ def test_distortion_loss_per_ray_positions_and_long_rays(hip):
 
 
 def test_projection_from_ndc_matches_reference(hip):
-    import utils
+    import zest_utils as utils
     inp, gold = gc.build("loss_side"), gc.load_golden("loss_side")
     w, pts = G(inp["weights"]).requires_grad_(True), G(inp["pts"]).requires_grad_(True)
     uv = utils.projection_from_ndc(G(inp["w2c"]), inp["H"], inp["W"], inp["f"], w, pts)

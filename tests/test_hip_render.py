@@ -21,7 +21,7 @@ CHAIN2 = ("raw_pts_pp", "rgb_map_pp_dy")
 
 
 def build_nets(sc, net_type="v0"):
-    import networks
+    import zest_networks as networks
     sf = sc["scene_flow"]
     ns = networks.MVSNeRF(D=8, W=256, input_ch_pts=gc.PE_PTS, output_ch=4, input_ch_views=gc.PE_DIR,
                           input_ch_feat=sc["feat_dim"], skips=[4], net_type=net_type, sceneflow=sf,
@@ -37,15 +37,16 @@ def build_nets(sc, net_type="v0"):
     return ns.to("cuda:0"), nd
 
 
-def render_scene(sc, c, precision=32, monkeypatch=None, maps_only=False, dtype16="bf16", net_type="v0"):
+def render_scene(sc, c, precision=32, monkeypatch=None, maps_only=False, dtype16="bf16", net_type="v0",
+                 fp32_exact=False):
     """renderer.rendering on a scene dict of golden_cases.render_inputs with the flags of case dict c."""
-    import networks
-    import renderer
+    import zest_networks as networks
+    import zest_renderer as renderer
     sf = sc["scene_flow"]
     ns, nd = build_nets(sc, net_type)
     args = SimpleNamespace(netchunk=1024, feat_dim=sc["feat_dim"], feat_dim_dy=24, img_downscale=1.0,
                            use_color_volume=False, net_type=net_type, precision=precision,
-                           zest_maps_only=maps_only, zest_dtype16=dtype16)
+                           zest_maps_only=maps_only, zest_dtype16=dtype16, zest_fp32_exact=fp32_exact)
     cam = {"w2cs": G(sc["w2cs"]), "intrinsics": G(sc["intrinsics"])}
     dy = sf and sc["use_mvs_dy"]
     nb_cam = {"w2cs": G(sc["nb_w2cs"]), "intrinsics": G(sc["nb_intrinsics"])} if dy else None
@@ -68,13 +69,17 @@ def render_scene(sc, c, precision=32, monkeypatch=None, maps_only=False, dtype16
             raw_noise_std=c.get("raw_noise_std", 0))
 
 
-def call_rendering(case, precision=32, monkeypatch=None, maps_only=False, dtype16="bf16"):
-    return render_scene(gc.build(case), gc.CASES[case], precision, monkeypatch, maps_only, dtype16)
+def call_rendering(case, precision=32, monkeypatch=None, maps_only=False, dtype16="bf16", fp32_exact=False):
+    return render_scene(gc.build(case), gc.CASES[case], precision, monkeypatch, maps_only, dtype16,
+                        fp32_exact=fp32_exact)
 
 
+@pytest.mark.parametrize("exact", [False, True], ids=["f16x3", "exact"])
 @pytest.mark.parametrize("case", RENDER_CASES)
-def test_rendering_matches_reference_fp32(hip, case, monkeypatch):
-    ret = call_rendering(case, 32, monkeypatch)
+def test_rendering_matches_reference_fp32(hip, case, exact, monkeypatch):
+    """Every key of the reference's result dict, all ten scenes, both fp32-mode MLP kernels: split-fp16
+    pairs (the default) and exact fp32 products (args.zest_fp32_exact)."""
+    ret = call_rendering(case, 32, monkeypatch, fp32_exact=exact)
     gold = gc.load_golden(case)
     assert sorted(ret.keys()) == gold["__keys__"].tolist()
     none_keys = set(x for x in gold["__none_keys__"].tolist() if x)
@@ -123,9 +128,9 @@ def test_fused_renderer(hip, case):
 
 
 def test_module_api(hip):
-    import networks
-    import renderer
-    import utils
+    import zest_networks as networks
+    import zest_renderer as renderer
+    import zest_utils as utils
     # MVSNeRF.forward on [1, M, C] like the reference's batchify call
     inp, gold = gc.build("mlp_static_sf_mvs40"), gc.load_golden("mlp_static_sf_mvs40")
     net = networks.MVSNeRF(D=8, W=256, input_ch_pts=63, input_ch_views=27, input_ch_feat=40,
@@ -184,7 +189,7 @@ def test_build_rays_matches_reference(hip, case):
     import sys
     sys.path.insert(0, os.path.join(gc.ROOT, "tools"))
     import gen_golden
-    import utils
+    import zest_utils as utils
     got = gen_golden.run_rays(utils, gc.CASES[case], gc.build(case), wrap=G)
     gold = gc.load_golden(case)
     assert sorted(got) == sorted(gold)
@@ -193,7 +198,7 @@ def test_build_rays_matches_reference(hip, case):
 
 
 def test_get_ndc_coordinate(hip):
-    import utils
+    import zest_utils as utils
     from oracle import zest_oracle as zo
     inp = gc.build("rays_random")
     pts = gc.zs.rng(9).uniform(-2, 2, size=(1, 5, 7, 3)).astype(np.float32) + np.array([0, 0, 4], np.float32)
@@ -220,8 +225,8 @@ def test_ray_permutation_commutes(hip):
 def test_fused_view_counts(hip, V):
     """Fused renderer with feature operands of one k-tile (V <= 6) and two (V <= 14), against the
     per-op bf16 path and the oracle on a seeded scene with V source views."""
-    import networks
-    import renderer
+    import zest_networks as networks
+    import zest_renderer as renderer
     import oracle_run as orun
     sc = gc.render_inputs(900 + V, R=24, S=40, V=V, use_mvs=True)
     ns, _ = build_nets(sc)

@@ -26,7 +26,7 @@ def _oracle_cost(inp):
 def test_homo_warp_given_grid_matches_reference(hip):
     import sys, os
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
-    import utils
+    import zest_utils as utils
     from oracle import zest_oracle as zo
     inp, gold = gc.build("homo_warp"), gc.load_golden("homo_warp")
     feats, imgs = G(inp["feats"]), G(inp["imgs"])
@@ -44,7 +44,7 @@ def test_homo_warp_given_grid_matches_reference(hip):
 
 def test_homo_warp_builds_the_grid(hip):
     """Own grid construction (utils.py:57-89 restated) against the oracle, then the same warp."""
-    import utils
+    import zest_utils as utils
     from oracle import zest_oracle as zo
     inp, gold = gc.build("homo_warp"), gc.load_golden("homo_warp")
     feats = G(inp["feats"])
@@ -60,7 +60,7 @@ def test_homo_warp_builds_the_grid(hip):
 
 @pytest.mark.parametrize("V,pad,seed", [(3, 2, 61), (4, 0, 62), (2, 5, 64)])
 def test_build_volume_cost(hip, V, pad, seed):
-    import networks
+    import zest_networks as networks
     inp = gc.cost_inputs(seed, V=V, pad=pad)
     want_feat, want_masks = _oracle_cost(inp)
     net = networks.MVSNet.__new__(networks.MVSNet)          # the method needs no parameters
@@ -83,7 +83,7 @@ def test_volume_builder_end_to_end_shapes(hip):
     """MVSNet.forward with random weights: FeatureNet -> HIP plane sweep -> CostRegNet gives the
     8-channel encoding volume the renderer consumes (convolutions: parity unpinned, see module
     docstring)."""
-    import networks
+    import zest_networks as networks
     torch.manual_seed(0)
     net = networks.MVSNet().cuda().eval()
     inp = gc.cost_inputs(65, V=3, H=16, W=24, pad=4)

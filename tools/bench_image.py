@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import torch
 import bench  # noqa: F401  (sets sys.path for the package)
-import networks
+import zest_networks as networks
 import test_generators as tg
 
 

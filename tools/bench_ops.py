@@ -14,7 +14,7 @@ import numpy as np
 import torch
 import bench
 import zest_hip
-import utils as zutils
+import zest_utils as zutils
 
 HBM_PEAK, F32_MFMA_PEAK, BF16_PEAK = 8000.0, 157.3, 2500.0      # GB/s, TFLOP/s, TFLOP/s
 

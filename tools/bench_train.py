@@ -18,8 +18,8 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 import bench
-import networks
-import renderer
+import zest_networks as networks
+import zest_renderer as renderer
 
 
 def main():

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 import bench
 import zest_hip
-import renderer
+import zest_renderer as renderer
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "nsff_static_1024x128"
 d = bench.build_workload(wl, 1, torch.device("cuda:0"))

@@ -21,7 +21,7 @@ import torch.nn as nn
 
 import zest_hip
 
-__all__ = ["Embedding", "Renderer", "Renderer_linear", "MVSNeRF", "resolve_precision",
+__all__ = ["Embedding", "Renderer", "Renderer_linear", "MVSNeRF", "resolve_precision", "inference_precision",
            "ActivatedBatchNorm", "ConvBnReLU", "ConvBnReLU3D", "FeatureNet", "CostRegNet", "MVSNet",
            "MVSNeRF_G", "DyMVSNeRF_G"]
 
@@ -46,6 +46,18 @@ def resolve_precision(args=None):
             raise ValueError("args.zest_dtype16=%r: expected 'bf16' or 'f16'" % (name,))
         return _PREC_BY_NAME[name]
     return zest_hip.PREC_F32
+
+
+def inference_precision(prec, args=None):
+    """Operand type of an inference (no-grad) MLP launch in mode `prec`: fp32 mode runs on split-fp16
+    pairs (ZEST_PREC_F16X3: same 1e-4 / 1e-3 agreement with the fp32 reference as the exact-product
+    kernel at ~7x its speed) unless exact fp32 products are asked for with `args.zest_fp32_exact`
+    or ZEST_FP32_EXACT=1 (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain, no fp16 range limit)."""
+    if prec != zest_hip.PREC_F32:
+        return prec
+    if os.environ.get("ZEST_FP32_EXACT", "") not in ("", "0") or getattr(args, "zest_fp32_exact", False):
+        return zest_hip.PREC_F32
+    return zest_hip.PREC_F16X3
 
 
 class Embedding(nn.Module):
@@ -119,7 +131,7 @@ class _MlpBase(nn.Module):
             raise RuntimeError("zest MLP: use MVSNeRF.forward (it owns the `nerf.` parameter names the "
                                "training path needs)")
         desc = self._desc()
-        prec = resolve_precision() if precision is None else precision
+        prec = inference_precision(resolve_precision()) if precision is None else precision
         return zest_hip.mlp_fwd(desc, prec, self.packed(prec), x)
 
     def forward(self, x):
@@ -422,8 +434,8 @@ class MVSNeRF_G(_Generator):
         self.N_rays, self.N_samples, self.args = args.batch_size, args.N_samples, args
 
     def forward(self, x, step=0, time_codes=None):
-        import utils
-        from renderer import rendering
+        import zest_utils as utils
+        from zest_renderer import rendering
         imgs = x['images']
         depths = x['depths_h'] if 'depths_h' in x else x['depths']
         cams = {'w2cs': x['w2cs'], 'intrinsics': x['intrinsics']}
@@ -474,7 +486,7 @@ class DyMVSNeRF_G(_Generator):
         return sc
 
     def _render(self, sc, rays, time_codes, **kw):
-        from renderer import rendering
+        from zest_renderer import rendering
         rays_pts, rays_dir, rays_ndc, depth_candidates = rays
         return rendering(self.args, rays_pts, rays_ndc, depth_candidates, rays_dir,
                          volume_feature_static=sc['vol_s'], volume_feature_dynamic=sc['vol_d'],
@@ -486,7 +498,7 @@ class DyMVSNeRF_G(_Generator):
                          num_frames=sc['num_frames'], **kw)
 
     def forward(self, x, step=0, time_codes=None):
-        import utils
+        import zest_utils as utils
         a = self.args
         chain_5frames = bool(a.with_chain_loss and step > self.decay_iteration * 1000 * 2)
         extra = a.num_extra_samples if (a.use_motion_mask and step < self.decay_iteration * 1000) else 0
@@ -512,7 +524,7 @@ class DyMVSNeRF_G(_Generator):
         (reference networks.py:595-720).  In a torch.distributed group the chunks are split into
         contiguous runs per rank, rendered locally and exchanged with ONE all-gather per image;
         every list then holds a single tensor covering the image."""
-        import utils
+        import zest_utils as utils
         import zest_parallel
         a = self.args
         with torch.no_grad():

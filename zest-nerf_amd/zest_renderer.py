@@ -20,8 +20,8 @@ Two execution plans:
 import torch
 
 import zest_hip
-from networks import MVSNeRF, resolve_precision
-from utils import images_channels_last, volume_channels_last
+from zest_networks import MVSNeRF, inference_precision, resolve_precision
+from zest_utils import images_channels_last, volume_channels_last
 
 __all__ = ["rendering", "raw2outputs", "raw2outputs_blending", "raw2alpha", "depth2dist",
            "compute_2d_prob"]
@@ -223,16 +223,18 @@ def rendering(args, rays_pts, rays_ndc, depth_candidates, rays_dir,
     # it on split-fp16 operand pairs (fp32-class results); a call that records a gradient takes the
     # complete plan below, whose stages have backward kernels.
     if getattr(args, "zest_maps_only", False) and (val or not scene_flow) and not train:
-        fused_prec = zest_hip.PREC_F16X3 if prec == zest_hip.PREC_F32 else prec
+        fused_prec = zest_hip.PREC_F16X3 if prec == zest_hip.PREC_F32 else prec     # no exact-product fused kernel
         return _render_maps_fused(fused_prec, rays_ndc, ndc, pts, z, dirs, net_s, network_fn_dy, scene_flow,
                                   volume_feature_static, volume_feature_dynamic, imgs,
                                   neighbour_frames, im_cam_mat, nb_cam_mat, embedding_xyzt,
                                   embedding_dir, ref_frame_idx, white_bkgd, raw_noise_std)
 
+    mlp_prec = inference_precision(prec, args)
+
     def mlp(net, x):
         if train:
             return za.mlp_apply(net, x)
-        return zest_hip.mlp_fwd(net.desc(), prec, net.packed(prec), x)
+        return zest_hip.mlp_fwd(net.desc(), mlp_prec, net.packed(mlp_prec), x)
 
     def encode(views, volume, ndc3, t=None):
         if train:

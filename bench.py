@@ -140,14 +140,12 @@ def psnr_report(build_rgb, ref_rgb, seed=0):
             "criterion_db": 0.05, "sample": "%d rays of the workload; target = reference colours + N(0, 0.05^2)" % r.shape[0]}
 
 
-def cpu_baseline(d, budget_s=15.0, build_ret=None):
-    """Oracle (reference op sequence, PyTorch-CPU fp32, all host cores) on the first rays of the
-    same workload; bounded to ~budget_s seconds.  With build_ret (the GPU result of the same
-    batch) also returns the PSNR report of its colours against the oracle's."""
+def oracle_call(d, rays=256):
+    """-> f() that runs the oracle (reference op sequence, PyTorch-CPU fp32) on the first `rays` rays of the
+    workload and returns its result dict; and the ray count."""
     from oracle import zest_oracle as zo
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
     sc, sf = d.sc, d.cfg["scene_flow"]
-    Rc = min(d.R, 256)
+    Rc = min(d.R, rays)
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
     st = lambda net: {k: v.detach().cpu() for k, v in net.state_dict().items()}
     ns = zo.Net(st(d.net_s), zo.MlpSpec(63, 27, d.args.feat_dim, sf, True, d.cfg["use_mvs"]))
@@ -160,18 +158,30 @@ def cpu_baseline(d, budget_s=15.0, build_ret=None):
               nb_imgs=T(sc["nb_imgs"])[0] if sf else None, cams=cams, nb_cams=nb, scene_flow=sf,
               val=True, ref_frame_idx=0.1, num_frames=24, explicit=False)
     a = [T(sc[k])[0, :Rc] for k in ("rays_pts", "rays_ndc", "depth_candidates", "rays_dir")]
+
+    def run():
+        with torch.no_grad():
+            return zo.rendering(*a, ns, nd, **kw)
+    return run, Rc
+
+
+def cpu_baseline(d, budget_s=15.0, build_ret=None):
+    """Oracle (reference op sequence, PyTorch-CPU fp32, all host cores) on the first rays of the
+    same workload; bounded to ~budget_s seconds.  With build_ret (the GPU result of the same
+    batch) also returns the PSNR report of its colours against the oracle's."""
+    sf = d.cfg["scene_flow"]
+    run, Rc = oracle_call(d, 256)
     # the GPU box gives one GPU's job a 16-core share of the host; more threads only thrash
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     torch.set_num_threads(max(1, min(16, ncpu)))
-    with torch.no_grad():
-        ref = zo.rendering(*a, ns, nd, **kw)                 # warm-up
-        n, t0 = 0, time.perf_counter()
-        while True:
-            zo.rendering(*a, ns, nd, **kw)
-            n += 1
-            el = time.perf_counter() - t0
-            if el > budget_s or n >= 200:
-                break
+    ref = run()                                              # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        run()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 200:
+            break
     out = {"value": Rc * n / el, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
            "sample": "%d calls of %d rays x %d samples of the same workload (oracle, torch-CPU fp32, "
                      "grid_sample/linear/cumprod op sequence of the reference)" % (n, Rc, d.S)}

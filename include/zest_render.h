@@ -49,7 +49,8 @@ typedef struct zest_mlp_desc {
     int32_t in_ch_views;  /* encoded direction width: 27                                  */
     int32_t use_feat;     /* 1: input carries features, trunk is modulated by pts_bias    */
     int32_t net_type;     /* 0 = 'v0' multiplicative modulation; 2 = 'v2' additive,       */
-                          /*     relu(alpha), sigmoid(rgb)                                */
+                          /*     relu(alpha), sigmoid(rgb); 3 = the 'v2' trunk with raw   */
+                          /*     outputs (Renderer_linear.forward_alpha; zest_mlp_fwd only) */
     int32_t head;         /* ZEST_HEAD_*                                                   */
 } zest_mlp_desc;
 
@@ -75,10 +76,12 @@ int         zest_device_info(int *cu_count, int *clock_khz, char *name, size_t n
 /* ---- compositing -------------------------------------------------------------
  * Replaces depth2dist + raw2outputs + raw2alpha (reference renderer.py:74-164).
  * raw [R,S,4] (rgb logits, sigma), z [R,S], rays_dir [R,3] (un-normalised; the
- * sample distance is dz * |dir|, last sample 1e10*|dir|).  noise [R,S] or NULL is
+ * sample distance is dz * |dir|, last sample 1e10*|dir|).  dists [R,S] or NULL: when given,
+ * the sample distances are taken from it instead (the `dists` argument of the reference's
+ * raw2outputs, whatever produced it) and rays_dir may be NULL.  noise [R,S] or NULL is
  * added to sigma after scaling by noise_std.  Any output pointer may be NULL.
  * rgb_map [R,3], depth/acc/disp [R], weights/alpha [R,S]. */
-int zest_composite_fwd(const float *raw, const float *z, const float *rays_dir,
+int zest_composite_fwd(const float *raw, const float *z, const float *rays_dir, const float *dists,
                        const float *noise, float noise_std, int white_bkgd,
                        int R, int S,
                        float *rgb_map, float *depth_map, float *acc_map, float *disp_map,
@@ -89,7 +92,7 @@ int zest_composite_fwd(const float *raw, const float *z, const float *rays_dir,
  * dynamic-only rgb_map_fg [R,3], depth_map_fg [R], weights_fg [R,S]; weights_dy [R,S]
  * (dynamic share of the blended weights) and its per-ray sum weights_dd_sum [R]. */
 int zest_composite_blend_fwd(const float *raw_dy, const float *raw_st, const float *blend,
-                             const float *z, const float *rays_dir,
+                             const float *z, const float *rays_dir, const float *dists,
                              const float *noise, float noise_std, int R, int S,
                              float *rgb_map, float *depth_map, float *rgb_map_fg,
                              float *depth_map_fg, float *weights_fg, float *weights_dy,
@@ -201,9 +204,9 @@ int zest_ndc_fwd(const float *pts, int M, const float *w2c, const float *k, floa
  * Gradient of zest_composite_fwd with respect to raw, given the gradients of the outputs
  * the reference's losses consume: rgb_map [R,3], depth_map [R], acc_map [R], weights [R,S]
  * (any may be NULL = zero).  disp_map and alpha have no consumer and carry no gradient.
- * Same raw / z / rays_dir / noise as the forward call.  g_raw [R,S,4]. */
-int zest_composite_bwd(const float *raw, const float *z, const float *rays_dir, const float *noise,
-                       float noise_std, int white_bkgd, int R, int S, const float *g_rgb_map,
+ * Same raw / z / rays_dir / dists / noise as the forward call.  g_raw [R,S,4]. */
+int zest_composite_bwd(const float *raw, const float *z, const float *rays_dir, const float *dists,
+                       const float *noise, float noise_std, int white_bkgd, int R, int S, const float *g_rgb_map,
                        const float *g_depth_map, const float *g_acc_map, const float *g_weights,
                        float *g_raw, void *stream);
 
@@ -211,8 +214,8 @@ int zest_composite_bwd(const float *raw, const float *z, const float *rays_dir, 
  * depth_map_fg, weights_fg, weights_dy (NULL = zero; weights_dd_sum is detached in the
  * reference) -> g_raw_dy, g_raw_st [R,S,4], g_blend [R,S]. */
 int zest_composite_blend_bwd(const float *raw_dy, const float *raw_st, const float *blend,
-                             const float *z, const float *rays_dir, const float *noise,
-                             float noise_std, int R, int S, const float *g_rgb_map,
+                             const float *z, const float *rays_dir, const float *dists,
+                             const float *noise, float noise_std, int R, int S, const float *g_rgb_map,
                              const float *g_depth_map, const float *g_rgb_map_fg,
                              const float *g_depth_map_fg, const float *g_weights_fg,
                              const float *g_weights_dy, float *g_raw_dy, float *g_raw_st,

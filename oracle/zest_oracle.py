@@ -182,6 +182,27 @@ def mlp_forward(state, x, spec, prefix="nerf."):
     return torch.cat([rgb, alpha] + extras, -1)
 
 
+def mlp_forward_alpha(state, x, spec, prefix="nerf."):
+    """Density-only pass, x [M, in_ch_pts + in_ch_feat] -> [M, 1].  Restates Renderer.forward_alpha
+    (/root/reference/networks.py:134-147: multiplicative modulation, relu on alpha) and
+    Renderer_linear.forward_alpha (networks.py:266-280: additive modulation, raw alpha); both always
+    modulate with pts_bias(features), whatever use_mvs says."""
+    def lin(name, h):
+        return F.linear(h, state[prefix + name + ".weight"], state[prefix + name + ".bias"])
+
+    P = spec.in_ch_pts
+    pts, feats = x[:, :P], x[:, P:P + spec.in_ch_feat]
+    m = lin("pts_bias", feats)
+    h = pts
+    for i in range(spec.D):
+        h = lin("pts_linears.%d" % i, h)
+        h = torch.relu(h * m if spec.net_type == "v0" else h + m)
+        if i in spec.skips:
+            h = torch.cat([pts, h], -1)
+    alpha = lin("alpha_linear", h)
+    return torch.relu(alpha) if spec.net_type == "v0" else alpha
+
+
 # ------------------------------------------------------------- compositing (a2,a12,a13)
 def sample_dists(z, dir_norm):
     """z [R,S], dir_norm [R,1] -> [R,S]; last interval 1e10, all scaled by |d|.
@@ -242,20 +263,24 @@ class Net:
 
 
 def build_mlp_input(net, pts_world, ndc, view_dir, volume=None, imgs=None, cams=None,
-                    frame_idx=None, explicit=True):
+                    frame_idx=None, explicit=True, time_codes=None):
     """Assemble the per-sample MLP input [R,S,in_ch] = PE(point[,t]) | features | PE(dir).
 
     pts_world, ndc [R,S,3]; view_dir [R,3] already rotated into the reference camera.
     Restates prepare_pts / prepare_dynamic_pts / gen_pts_feats,
     /root/reference/renderer.py:51-72,246-318: the time index is appended as a 4th
     coordinate before encoding; the volume is looked up at ndc (without t) and the
-    colours at the un-displaced world points.
+    colours at the un-displaced world points.  time_codes [1,T] or [T] (Neural3D video mode,
+    renderer.py:269-273): sigmoid of the frame's latent code, the same for every sample, right
+    after the encoded point.
     """
     R, S, _ = ndc.shape
     p = ndc
     if frame_idx is not None:
         p = torch.cat([ndc, torch.full_like(ndc[..., :1], frame_idx)], -1)
     cols = [embed(p, net.n_freq_pts)]
+    if time_codes is not None:
+        cols.append(torch.sigmoid(time_codes).reshape(1, 1, -1).expand(R, S, -1))
     feats = None
     if volume is not None:
         f8 = volume_lookup(volume, ndc, explicit)
@@ -275,7 +300,7 @@ def rendering(rays_pts, rays_ndc, z, rays_dir, net_static, net_dynamic=None,
               vol_static=None, vol_dynamic=None, imgs=None, nb_imgs=None,
               cams=None, nb_cams=None, scene_flow=False, val=False, chain_bwd=False,
               chain_5frames=False, ref_frame_idx=None, num_frames=None,
-              white_bkgd=False, raw_noise_std=0.0, noise=None, explicit=True):
+              white_bkgd=False, raw_noise_std=0.0, noise=None, explicit=True, time_codes=None):
     """Flat-tensor restatement of rendering(), /root/reference/renderer.py:579-626.
 
     rays_pts, rays_ndc [R,S,3]; z [R,S]; rays_dir [R,3] (un-normalised).
@@ -295,7 +320,7 @@ def rendering(rays_pts, rays_ndc, z, rays_dir, net_static, net_dynamic=None,
 
     use_noise = raw_noise_std > 0
     x, _, feats = build_mlp_input(net_static, rays_pts, rays_ndc, vdir(cams), vol_static, imgs,
-                                  cams, None, explicit)
+                                  cams, None, explicit, time_codes)          # static net only (renderer.py:351)
     raw_s = run_mlp(net_static, x)
     raw_rgba = raw_s[..., :4]
     blend = raw_s[..., 4] if scene_flow else None

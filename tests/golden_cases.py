@@ -142,15 +142,19 @@ def cost_inputs(seed, V=3, H=18, W=24, D=6, pad=2, spread=0.35):
 
 # --------------------------------------------------------------- rendering cases
 def render_inputs(seed, R=32, S=16, V=3, use_mvs=True, scene_flow=False, use_mvs_dy=True,
-                  lively=True):
-    """Small scene (24x32 images, 8x10x12 volume) + seeded MLP weights."""
+                  lively=True, time_dim=0):
+    """Small scene (24x32 images, 8x10x12 volume) + seeded MLP weights.  time_dim > 0: the static net
+    takes that many time-code channels after the encoded point (Neural3D video mode, reference
+    train.py:91-113, renderer.py:269-273) and the scene carries one latent code `time_codes` [1,T]."""
     sc = zs.make_scene(seed, R, S, H=24, W=32, V=V, V_dy=4, pad=2, vol_depth=8, focal=30.0,
                        static_volume=use_mvs, dynamic=scene_flow)
     feat_dim = 8 + 4 * V
-    lay_s = zs.mlp_layout(PE_PTS, PE_DIR, feat_dim, scene_flow, True, use_mvs)
+    lay_s = zs.mlp_layout(PE_PTS + time_dim, PE_DIR, feat_dim, scene_flow, True, use_mvs)
     sc["state_static"] = zs.fill_mlp_state(lay_s, seed + 1, lively=lively)
     sc.update(feat_dim=feat_dim, feat_dim_dy=24, use_mvs=use_mvs, use_mvs_dy=use_mvs_dy,
-              scene_flow=scene_flow)
+              scene_flow=scene_flow, time_dim=time_dim)
+    if time_dim:
+        sc["time_codes"] = zs.rng(seed + 4).standard_normal((1, time_dim)).astype(np.float32)
     if scene_flow:
         lay_d = zs.mlp_layout(PE_XYZT, PE_DIR, 24, True, False, use_mvs_dy)
         sc["state_dynamic"] = zs.fill_mlp_state(lay_d, seed + 2, lively=lively)
@@ -212,6 +216,8 @@ CASES = {
                                 use_mvs_dy=False),
     "grad_zest_5f": dict(kind="render_grad", seed=41, scene_flow=True, chain_5frames=True),
     "grad_static": dict(kind="render_grad", seed=42, use_mvs=True, white_bkgd=True),
+    "render_static_timecodes": dict(kind="render", seed=43, use_mvs=True, time_dim=8),
+    "grad_static_timecodes": dict(kind="render_grad", seed=44, use_mvs=True, time_dim=8),
 }
 
 REF_FRAME_IDX, NUM_FRAMES = 0.1, 24
@@ -261,7 +267,7 @@ def build(case):
     if k in ("render", "render_grad"):
         return render_inputs(c["seed"], use_mvs=c.get("use_mvs", True),
                              scene_flow=c.get("scene_flow", False),
-                             use_mvs_dy=c.get("use_mvs_dy", True))
+                             use_mvs_dy=c.get("use_mvs_dy", True), time_dim=c.get("time_dim", 0))
     raise KeyError(k)
 
 

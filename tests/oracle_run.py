@@ -29,7 +29,7 @@ def spec_of(P, Fd, sceneflow, static, use_mvs, net_type="v0"):
 def render_nets(sc, dtype=torch.float32):
     sf = sc["scene_flow"]
     ns = zo.Net(state_t(sc["state_static"], dtype),
-                spec_of(gc.PE_PTS, sc["feat_dim"], sf, True, sc["use_mvs"]))
+                spec_of(gc.PE_PTS + sc.get("time_dim", 0), sc["feat_dim"], sf, True, sc["use_mvs"]))
     nd = None
     if sf:
         nd = zo.Net(state_t(sc["state_dynamic"], dtype),
@@ -54,7 +54,7 @@ def oracle_render(c, sc, dtype=torch.float32, explicit=True):
         chain_bwd=c.get("chain_bwd", False), chain_5frames=c.get("chain_5frames", False),
         ref_frame_idx=gc.REF_FRAME_IDX, num_frames=gc.NUM_FRAMES,
         white_bkgd=c.get("white_bkgd", False), raw_noise_std=c.get("raw_noise_std", 0),
-        noise=noise, explicit=explicit)
+        noise=noise, explicit=explicit, time_codes=T(sc["time_codes"], dtype) if sc.get("time_dim", 0) else None)
 
 
 def rays_pixels(c, inp):
@@ -111,6 +111,9 @@ def run(case, dtype=torch.float32, explicit=True):
             spec = spec_of(inp["P"], inp["Fd"], inp["sceneflow"], inp["static"], inp["use_mvs"],
                            inp["net_type"])
             out["y"] = zo.mlp_forward(state_t(inp["state"], dtype), T(inp["x"], dtype)[0], spec)
+            if inp["use_mvs"] or inp["net_type"] == "v2":
+                out["alpha_only"] = zo.mlp_forward_alpha(state_t(inp["state"], dtype),
+                                                         T(inp["x"], dtype)[0, :, :inp["P"] + inp["Fd"]], spec)
         elif k == "loss_side":
             pass                                    # needs autograd: below
         elif k == "homo_warp":
@@ -177,6 +180,9 @@ def oracle_render_grads(case, dtype=torch.float32):
     t = lambda k: T(sc[k], dtype)[0]
     vol_s = t("vol_static").requires_grad_(True) if sc["use_mvs"] else None
     vol_d = t("vol_dynamic").requires_grad_(True) if (sf and sc["use_mvs_dy"]) else None
+    tc = T(sc["time_codes"], dtype).requires_grad_(True) if sc.get("time_dim", 0) else None
+    if tc is not None:
+        leaves["time_codes"] = tc
     if vol_s is not None:
         leaves["vol_static"] = vol_s
     if vol_d is not None:
@@ -188,7 +194,8 @@ def oracle_render_grads(case, dtype=torch.float32):
                        nb_imgs=t("nb_imgs") if (sf and sc["use_mvs_dy"]) else None, cams=cams, nb_cams=nb_cams,
                        scene_flow=sf, val=False, chain_bwd=c.get("chain_bwd", False),
                        chain_5frames=c.get("chain_5frames", False), ref_frame_idx=gc.REF_FRAME_IDX,
-                       num_frames=gc.NUM_FRAMES, white_bkgd=c.get("white_bkgd", False), explicit=False)
+                       num_frames=gc.NUM_FRAMES, white_bkgd=c.get("white_bkgd", False), explicit=False,
+                       time_codes=tc)
     W = gc.loss_weights(c["seed"], {k: tuple(v.shape) for k, v in ret.items() if v is not None})
     loss = sum((T(W[k], dtype) * ret[k]).sum() for k in W)
     loss.backward()

@@ -43,3 +43,15 @@ def test_cpu_tensors_are_rejected():
     import zest_hip
     with pytest.raises(RuntimeError, match="runs only on a HIP device"):
         zest_hip.embed(torch.zeros(4, 3), 10)
+
+
+def test_library_is_not_older_than_its_sources():
+    """A failed rebuild must not go unnoticed: the shipped .so is at least as new as every source it is
+    built from (build_hip.py rebuilds what is stale; __graft_entry__.build() runs it)."""
+    import glob
+    pkg = os.path.join(ROOT, "zest-nerf_amd")
+    lib = os.path.join(pkg, "libzest_hip.so")
+    srcs = glob.glob(os.path.join(pkg, "csrc", "*.hip")) + glob.glob(os.path.join(pkg, "csrc", "*.cuh")) + \
+        glob.glob(os.path.join(pkg, "csrc", "*.h")) + [os.path.join(ROOT, "include", "zest_render.h")]
+    newest = max(srcs, key=os.path.getmtime)
+    assert os.path.getmtime(lib) >= os.path.getmtime(newest), "libzest_hip.so is older than %s: rebuild" % newest

@@ -118,10 +118,10 @@ def test_encode_backward(hip):
     gclose(vol.grad[0], vol_o.grad.numpy(), "g_volume")
 
 
-@pytest.mark.parametrize("case", ["grad_zest_5f", "grad_static"])
+@pytest.mark.parametrize("case", ["grad_zest_5f", "grad_static", "grad_static_timecodes"])
 def test_rendering_training_gradients(hip, case):
     """Whole train-mode rendering(): loss over every differentiable output, gradients of both
-    MLPs' parameters and both encoding volumes."""
+    MLPs' parameters, both encoding volumes and (Neural3D mode) the frame's time code."""
     import zest_networks as networks
     import zest_renderer as renderer
     from types import SimpleNamespace
@@ -134,6 +134,7 @@ def test_rendering_training_gradients(hip, case):
                            use_color_volume=False, net_type="v0", precision=32)
     cam = {"w2cs": G(sc["w2cs"]), "intrinsics": G(sc["intrinsics"])}
     nb_cam = {"w2cs": G(sc["nb_w2cs"]), "intrinsics": G(sc["nb_intrinsics"])} if sf else None
+    tc = G(sc["time_codes"]).requires_grad_(True) if sc.get("time_dim", 0) else None
     ret = renderer.rendering(
         args, G(sc["rays_pts"]), G(sc["rays_ndc"]), G(sc["depth_candidates"]), G(sc["rays_dir"]),
         volume_feature_static=vol_s, volume_feature_dynamic=vol_d, imgs=G(sc["imgs"]) if sc["use_mvs"] else None,
@@ -141,7 +142,7 @@ def test_rendering_training_gradients(hip, case):
         network_fn_dy=nd, embedding_pts=networks.Embedding(3, 10), embedding_xyzt=networks.Embedding(4, 10),
         embedding_dir=networks.Embedding(3, 4), chain_bwd=c.get("chain_bwd", False),
         chain_5frames=c.get("chain_5frames", False), ref_frame_idx=gc.REF_FRAME_IDX, num_frames=gc.NUM_FRAMES,
-        white_bkgd=c.get("white_bkgd", False), scene_flow=sf, val=False)
+        white_bkgd=c.get("white_bkgd", False), scene_flow=sf, val=False, time_codes=tc)
     W = gc.loss_weights(c["seed"], {k: tuple(v.shape[1:]) for k, v in ret.items() if v is not None})
     loss = sum((G(W[k]) * ret[k][0]).sum() for k in W)
     loss.backward()
@@ -158,6 +159,8 @@ def test_rendering_training_gradients(hip, case):
             for k, p in net.named_parameters():
                 if p.grad is not None:
                     got["%s.%s" % (tag, k)] = p.grad
+    if tc is not None:
+        got["time_codes"] = tc.grad
     if vol_s is not None:
         got["vol_static"] = vol_s.grad[0]
     if vol_d is not None:

@@ -176,3 +176,48 @@ def test_mlp_view_counts(hip, V):
     close(y32, want, name="fp32 V=%d" % V)
     y16 = zh.mlp_fwd(desc, zh.PREC_BF16, zh.mlp_pack(desc, zh.PREC_BF16, tab), G(x))
     close(y16, want, atol=3e-2 * np.abs(want).max(), rtol=3e-2, name="bf16 V=%d" % V)
+
+
+def test_channels_last_cache_hits_on_fresh_views(hip, monkeypatch):
+    """The generators hand `imgs[:, :-1]` (a NEW view object per chunk) to the renderer: the channels-last
+    copy must be made once per image, not once per chunk; an in-place update or a different slice misses."""
+    import zest_hip
+    import zest_utils
+    calls = []
+    real = zest_hip.images_to_cl
+    monkeypatch.setattr(zest_hip, "images_to_cl", lambda t: (calls.append(1), real(t))[1])
+    zest_utils._CL_CACHE.clear()
+    imgs = torch.rand(1, 4, 3, 12, 16, device="cuda")
+    a = zest_utils.images_channels_last(imgs[:, :-1])
+    b = zest_utils.images_channels_last(imgs[:, :-1])
+    assert a is b and len(calls) == 1
+    zest_utils.images_channels_last(imgs[:, 1:])              # another slice of the same memory
+    assert len(calls) == 2
+    imgs.mul_(0.5)                                            # new content: version counter moved
+    c = zest_utils.images_channels_last(imgs[:, :-1])
+    assert len(calls) == 3 and torch.equal(c[..., :3], imgs[0, :-1].permute(0, 2, 3, 1))
+    del imgs, a, b, c
+    fresh = torch.rand(1, 4, 3, 12, 16, device="cuda")        # may reuse the freed address: must not hit
+    d = zest_utils.images_channels_last(fresh[:, :-1])
+    assert torch.equal(d[..., :3], fresh[0, :-1].permute(0, 2, 3, 1))
+
+
+@pytest.mark.parametrize("case", ["mlp_static_mvs20", "mlp_static_sf_mvs40", "mlp_dynamic_mvs24", "mlp_v2_mvs20"])
+@pytest.mark.parametrize("exact", [False, True], ids=["f16x3", "exact"])
+def test_forward_alpha_matches_reference(hip, case, exact, monkeypatch):
+    """Renderer.forward_alpha / Renderer_linear.forward_alpha (reference networks.py:134-147, 266-280)
+    against the reference's own outputs (fixture key `alpha_only`), both fp32-mode kernels."""
+    import zest_networks as networks
+    monkeypatch.setenv("ZEST_FP32_EXACT", "1" if exact else "0")
+    inp, gold = gc.build(case), gc.load_golden(case)
+    net = networks.MVSNeRF(D=8, W=256, input_ch_pts=inp["P"], input_ch_views=gc.PE_DIR, input_ch_feat=inp["Fd"],
+                           net_type=inp["net_type"], sceneflow=inp["sceneflow"], static=inp["static"],
+                           use_mvs=inp["use_mvs"])
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in inp["state"].items()})
+    net = net.cuda()
+    with torch.no_grad():
+        a = net.forward_alpha(G(inp["x"])[..., :inp["P"] + inp["Fd"]])
+        y = net(G(inp["x"]))                        # the full forward still packs and runs its own variant
+    assert a.shape == (1, 64, 1)
+    close(a[0], gold["alpha_only"], name=case + "/forward_alpha")
+    close(y[0], gold["y"], name=case + "/forward after forward_alpha")

@@ -80,7 +80,7 @@ def test_mlp_split_fp16_ragged_and_tiny_values(hip):
 
 # ------------------------------------------------------------------- fused renderer, fixtures
 FUSED_CASES = ["render_static_mvs", "render_static_nomvs", "render_static_white", "render_zest_val",
-               "render_zest_nomvsdy"]
+               "render_zest_nomvsdy", "render_static_timecodes"]
 
 
 @pytest.mark.parametrize("case", FUSED_CASES)

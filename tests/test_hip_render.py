@@ -23,9 +23,9 @@ CHAIN2 = ("raw_pts_pp", "rgb_map_pp_dy")
 def build_nets(sc, net_type="v0"):
     import zest_networks as networks
     sf = sc["scene_flow"]
-    ns = networks.MVSNeRF(D=8, W=256, input_ch_pts=gc.PE_PTS, output_ch=4, input_ch_views=gc.PE_DIR,
-                          input_ch_feat=sc["feat_dim"], skips=[4], net_type=net_type, sceneflow=sf,
-                          static=True, use_mvs=sc["use_mvs"])
+    ns = networks.MVSNeRF(D=8, W=256, input_ch_pts=gc.PE_PTS + sc.get("time_dim", 0), output_ch=4,
+                          input_ch_views=gc.PE_DIR, input_ch_feat=sc["feat_dim"], skips=[4], net_type=net_type,
+                          sceneflow=sf, static=True, use_mvs=sc["use_mvs"])
     ns.load_state_dict({k: torch.from_numpy(v) for k, v in sc["state_static"].items()})
     nd = None
     if sf:
@@ -66,7 +66,8 @@ def render_scene(sc, c, precision=32, monkeypatch=None, maps_only=False, dtype16
             chain_bwd=c.get("chain_bwd", False), chain_5frames=c.get("chain_5frames", False),
             ref_frame_idx=gc.REF_FRAME_IDX, num_frames=gc.NUM_FRAMES,
             white_bkgd=c.get("white_bkgd", False), scene_flow=sf, val=c.get("val", False),
-            raw_noise_std=c.get("raw_noise_std", 0))
+            raw_noise_std=c.get("raw_noise_std", 0),
+            time_codes=G(sc["time_codes"]) if sc.get("time_dim", 0) else None)
 
 
 def call_rendering(case, precision=32, monkeypatch=None, maps_only=False, dtype16="bf16", fp32_exact=False):
@@ -106,7 +107,7 @@ def test_rendering_bf16_mode(hip, case, monkeypatch):
 
 
 FUSED_CASES = ["render_static_mvs", "render_static_nomvs", "render_static_white", "render_zest_val",
-               "render_zest_nomvsdy"]
+               "render_zest_nomvsdy"]      # (the time-code scene: tests/test_hip_precision.py, all three operand types)
 
 
 @pytest.mark.parametrize("case", FUSED_CASES)
@@ -249,3 +250,40 @@ def test_fused_view_counts(hip, V):
               name="fused~perop/%s V=%d" % (k, V))
         close(fused[k][0], want[k].numpy(), atol=6e-2 if "depth" in k else 2e-2, rtol=0,
               name="fused~oracle/%s V=%d" % (k, V))
+
+
+def test_raw2outputs_uses_the_callers_dists(hip):
+    """raw2outputs / raw2outputs_blending / raw2alpha take `dists` as the reference does (renderer.py:115,
+    166, 91): spacings that did NOT come from depth2dist (random, no 1e10 tail) give the oracle's result
+    for those spacings, forward and backward."""
+    import zest_renderer as renderer
+    from oracle import zest_oracle as zo
+    comp = gc.composite_inputs(123, R=20, S=70, dead_ray=False)
+    g = gc.zs.rng(124)
+    dists = g.uniform(0.01, 0.2, size=comp["z"].shape).astype(np.float32)
+    raw, z = torch.from_numpy(comp["raw"]), torch.from_numpy(comp["z"])
+    want = zo.composite(raw, z, torch.from_numpy(dists), white_bkgd=True)
+    with torch.no_grad():
+        got = renderer.raw2outputs(G(comp["raw"])[None], G(comp["z"])[None], G(dists)[None], white_bkgd=True)
+    for n, a, b in zip(("rgb_map", "disp_map", "acc_map", "weights", "depth_map", "alpha"), got, want):
+        close(a[0], b.numpy(), name="raw2outputs(dists)/" + n)
+    a, w = renderer.raw2alpha(torch.relu(G(comp["raw"])[None, ..., 3]), G(dists)[None])
+    close(a[0], want[5].numpy(), name="raw2alpha(dists)/alpha")
+    close(w[0], want[3].numpy(), name="raw2alpha(dists)/weights")
+    # backward through the same spacings
+    rg = G(comp["raw"])[None].requires_grad_(True)
+    out = renderer.raw2outputs(rg, G(comp["z"])[None], G(dists)[None])
+    (out[0].sum() + (out[3] * G(comp["z"])[None]).sum()).backward()
+    rc = raw.clone().requires_grad_(True)
+    o2 = zo.composite(rc, z, torch.from_numpy(dists))
+    (o2[0].sum() + (o2[3] * z).sum()).backward()
+    close(rg.grad[0], rc.grad.numpy(), atol=1e-4, rtol=1e-3, name="raw2outputs(dists) grad")
+    # blending
+    bl = gc.build("blend")
+    d2 = g.uniform(0.01, 0.2, size=bl["z"].shape).astype(np.float32)
+    wantb = zo.composite_blend(*[torch.from_numpy(bl[k]) for k in ("raw_dy", "raw_st", "blend", "z")], torch.from_numpy(d2))
+    with torch.no_grad():
+        gotb = renderer.raw2outputs_blending(G(bl["raw_dy"])[None], G(bl["raw_st"])[None], G(bl["blend"])[None],
+                                             G(bl["z"])[None], G(d2)[None])
+    for n, a, b in zip(("rgb_map", "depth_map", "rgb_map_fg", "depth_map_fg", "weights_fg", "weights_dy"), gotb, wantb):
+        close(a[0], b.numpy(), name="raw2outputs_blending(dists)/" + n)

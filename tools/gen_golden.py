@@ -111,6 +111,8 @@ def run_case(ref, name):
             net = ref_net(ref, inp["state"], inp["P"], inp["Fd"], inp["sceneflow"], inp["static"],
                           inp["use_mvs"], inp["net_type"])
             out["y"] = net(T(inp["x"])).numpy()[0]
+            if inp["use_mvs"] or inp["net_type"] == "v2":          # x carries the feature columns forward_alpha reads
+                out["alpha_only"] = net.forward_alpha(T(inp["x"])[..., :inp["P"] + inp["Fd"]]).numpy()[0]
         elif k == "loss_side":
             pass
         elif k == "homo_warp":
@@ -219,7 +221,8 @@ def run_render(ref, c, sc, want_grad=False):
     e_pts = ref.networks.Embedding(3, 10)
     e_xyzt = ref.networks.Embedding(4, 10)
     e_dir = ref.networks.Embedding(3, 4)
-    net_s = ref_net(ref, sc["state_static"], gc.PE_PTS, sc["feat_dim"], sf, True, sc["use_mvs"])
+    net_s = ref_net(ref, sc["state_static"], gc.PE_PTS + sc.get("time_dim", 0), sc["feat_dim"], sf, True, sc["use_mvs"])
+    tc = T(sc["time_codes"]).requires_grad_(want_grad) if sc.get("time_dim", 0) else None
     net_d = None
     if sf:
         net_d = ref_net(ref, sc["state_dynamic"], gc.PE_XYZT, 24, True, False, sc["use_mvs_dy"])
@@ -235,6 +238,8 @@ def run_render(ref, c, sc, want_grad=False):
     vol_s = T(sc["vol_static"]).requires_grad_(want_grad) if sc["use_mvs"] else None
     vol_d = T(sc["vol_dynamic"]).requires_grad_(want_grad) if (sf and sc["use_mvs_dy"]) else None
     if want_grad:
+        if tc is not None:
+            leaves["time_codes"] = tc
         if vol_s is not None:
             leaves["vol_static"] = vol_s
         if vol_d is not None:
@@ -263,7 +268,7 @@ def run_render(ref, c, sc, want_grad=False):
             chain_bwd=c.get("chain_bwd", False), chain_5frames=c.get("chain_5frames", False),
             ref_frame_idx=gc.REF_FRAME_IDX, num_frames=gc.NUM_FRAMES,
             white_bkgd=c.get("white_bkgd", False), scene_flow=sf, val=c.get("val", False),
-            raw_noise_std=std)
+            raw_noise_std=std, time_codes=tc)
     finally:
         torch.randn = real_randn
     if want_grad:

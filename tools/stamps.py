@@ -28,8 +28,8 @@ with torch.no_grad():
     for _ in range(steps):
         bench.render_step(d)
     torch.cuda.synchronize()
-rec_bytes = d.R * ((d.S + 31) // 32) * 80
-st = ws[rec_bytes:].view(torch.int64).cpu().numpy().reshape(-1, 8)
+stamp_bytes = 1024 * 8 * 8 * 8                 # csrc/fused.hip kStampBytes: the tail of the workspace
+st = ws[need - stamp_bytes:].view(torch.int64).cpu().numpy().reshape(-1, 8)
 st = st[st[:, 7] > 0]
 tot, enc, eng, comp, wait, issue, real, n = [st[:, i].astype(np.float64) for i in range(8)]
 vm, n = (st[:, 7] >> 16).astype(np.float64), (st[:, 7] & 0xFFFF).astype(np.float64)

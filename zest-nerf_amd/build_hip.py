@@ -91,7 +91,8 @@ def build(force=False, extra_flags=(), tag=None, only=None):
 
 
 if __name__ == "__main__":
-    # python build_hip.py [-f] [--tag NAME -DFOO=1 ...]
+    # python build_hip.py [-f] [--tag NAME -DFOO=1 ...] [--only obj1,obj2.hip,...]
     argv = sys.argv[1:]
     tag = argv[argv.index("--tag") + 1] if "--tag" in argv else None
-    print(build(force="-f" in argv, extra_flags=[a for a in argv if a.startswith("-D")], tag=tag))
+    only = argv[argv.index("--only") + 1].split(",") if "--only" in argv else None
+    print(build(force="-f" in argv, extra_flags=[a for a in argv if a.startswith("-D")], tag=tag, only=only))

@@ -11,24 +11,29 @@ namespace {
 
 constexpr int kWavesPerBlock = 4;
 
-__device__ __forceinline__ float sample_dist(const float *__restrict__ zr, int s, int S, float z,
-                                             float dnorm) {
+__device__ __forceinline__ float sample_dist(const float *__restrict__ zr, const float *__restrict__ dr, int s,
+                                             int S, float z, float dnorm) {
     // distance to the next sample; the last one is "infinite" (1e10), both scaled by |dir|
+    // (depth2dist, reference renderer.py:74-89) - or the caller's own spacings when it hands them in
+    if (dr) return dr[s];
     const float dz = (s + 1 < S) ? (zr[s + 1] - z) : 1e10f;
     return dz * dnorm;
 }
 
 __global__ __launch_bounds__(kWavesPerBlock *ZEST_WAVE) void composite_kernel(
     const float4 *__restrict__ raw, const float *__restrict__ z, const float *__restrict__ dir,
-    const float *__restrict__ noise, float noise_std, int white_bkgd, int R, int S,
+    const float *__restrict__ dists, const float *__restrict__ noise, float noise_std, int white_bkgd, int R, int S,
     float *__restrict__ rgb_map, float *__restrict__ depth_map, float *__restrict__ acc_map,
     float *__restrict__ disp_map, float *__restrict__ weights, float *__restrict__ alpha_out) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (r >= R) return;                                   // wave-uniform
-    const float dx = dir[3 * r], dy = dir[3 * r + 1], dzv = dir[3 * r + 2];
-    const float dnorm = sqrtf(dx * dx + dy * dy + dzv * dzv);
-    const float *zr = z + (size_t)r * S;
+    float dnorm = 0.0f;
+    if (!dists) {
+        const float dx = dir[3 * r], dy = dir[3 * r + 1], dzv = dir[3 * r + 2];
+        dnorm = sqrtf(dx * dx + dy * dy + dzv * dzv);
+    }
+    const float *zr = z + (size_t)r * S, *drow = dists ? dists + (size_t)r * S : nullptr;
     float carry = 1.0f, a_r = 0.f, a_g = 0.f, a_b = 0.f, a_d = 0.f, a_w = 0.f;
     for (int s0 = 0; s0 < S; s0 += 64) {
         const int s = s0 + lane;
@@ -40,7 +45,7 @@ __global__ __launch_bounds__(kWavesPerBlock *ZEST_WAVE) void composite_kernel(
             float sig = v.w;
             if (noise) sig += noise[(size_t)r * S + s] * noise_std;
             sig = fmaxf(sig, 0.f);
-            alpha = 1.0f - expf(-sig * sample_dist(zr, s, S, zz, dnorm));
+            alpha = 1.0f - expf(-sig * sample_dist(zr, drow, s, S, zz, dnorm));
             cr = zest_sigmoid(v.x), cg = zest_sigmoid(v.y), cb = zest_sigmoid(v.z);
         }
         const float f = on ? (1.0f - alpha + 1e-10f) : 1.0f;
@@ -71,15 +76,19 @@ __global__ __launch_bounds__(kWavesPerBlock *ZEST_WAVE) void composite_kernel(
 __global__ __launch_bounds__(kWavesPerBlock *ZEST_WAVE) void composite_blend_kernel(
     const float4 *__restrict__ raw_dy, const float4 *__restrict__ raw_st,
     const float *__restrict__ blend, const float *__restrict__ z, const float *__restrict__ dir,
-    const float *__restrict__ noise, float noise_std, int R, int S, float *__restrict__ rgb_map,
+    const float *__restrict__ dists, const float *__restrict__ noise, float noise_std, int R, int S,
+    float *__restrict__ rgb_map,
     float *__restrict__ depth_map, float *__restrict__ rgb_map_fg, float *__restrict__ depth_map_fg,
     float *__restrict__ weights_fg, float *__restrict__ weights_dy, float *__restrict__ wdd_sum) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (r >= R) return;
-    const float dx = dir[3 * r], dy = dir[3 * r + 1], dzv = dir[3 * r + 2];
-    const float dnorm = sqrtf(dx * dx + dy * dy + dzv * dzv);
-    const float *zr = z + (size_t)r * S;
+    float dnorm = 0.0f;
+    if (!dists) {
+        const float dx = dir[3 * r], dy = dir[3 * r + 1], dzv = dir[3 * r + 2];
+        dnorm = sqrtf(dx * dx + dy * dy + dzv * dzv);
+    }
+    const float *zr = z + (size_t)r * S, *drow = dists ? dists + (size_t)r * S : nullptr;
     float carry = 1.0f, carry_fg = 1.0f;
     float m_r = 0.f, m_g = 0.f, m_b = 0.f, m_d = 0.f, f_r = 0.f, f_g = 0.f, f_b = 0.f, f_d = 0.f,
           dd = 0.f;
@@ -94,7 +103,7 @@ __global__ __launch_bounds__(kWavesPerBlock *ZEST_WAVE) void composite_blend_ker
             const float b = blend[i];
             zz = zr[s];
             const float n = noise ? noise[i] * noise_std : 0.0f;
-            const float dist = sample_dist(zr, s, S, zz, dnorm);
+            const float dist = sample_dist(zr, drow, s, S, zz, dnorm);
             a_fg = 1.0f - expf(-fmaxf(vd.w + n, 0.f) * dist);
             a_d = a_fg * b;
             a_s = (1.0f - expf(-fmaxf(vs.w + n, 0.f) * dist)) * (1.0f - b);
@@ -146,36 +155,36 @@ __global__ __launch_bounds__(kWavesPerBlock *ZEST_WAVE) void weighted_complement
 
 }  // namespace
 
-extern "C" int zest_composite_fwd(const float *raw, const float *z, const float *rays_dir,
+extern "C" int zest_composite_fwd(const float *raw, const float *z, const float *rays_dir, const float *dists,
                                   const float *noise, float noise_std, int white_bkgd, int R, int S,
                                   float *rgb_map, float *depth_map, float *acc_map, float *disp_map,
                                   float *weights, float *alpha, void *stream) {
-    ZEST_CHECK_ARG(raw && z && rays_dir, "zest_composite_fwd: raw, z and rays_dir are required");
+    ZEST_CHECK_ARG(raw && z && (rays_dir || dists), "zest_composite_fwd: raw, z and rays_dir (or dists) are required");
     ZEST_CHECK_ARG(R >= 0 && S >= 1, "zest_composite_fwd: bad shape R=%d S=%d", R, S);
     ZEST_CHECK_ARG(((uintptr_t)raw & 15) == 0, "zest_composite_fwd: raw must be 16-byte aligned");
     if (R == 0) return 0;
     hipLaunchKernelGGL(composite_kernel, dim3(zest_div_up(R, kWavesPerBlock)),
                        dim3(kWavesPerBlock * ZEST_WAVE), 0, (hipStream_t)stream,
-                       (const float4 *)raw, z, rays_dir, noise, noise_std, white_bkgd, R, S,
+                       (const float4 *)raw, z, rays_dir, dists, noise, noise_std, white_bkgd, R, S,
                        rgb_map, depth_map, acc_map, disp_map, weights, alpha);
     ZEST_RETURN_LAUNCH("zest_composite_fwd");
 }
 
 extern "C" int zest_composite_blend_fwd(const float *raw_dy, const float *raw_st,
                                         const float *blend, const float *z, const float *rays_dir,
-                                        const float *noise, float noise_std, int R, int S,
+                                        const float *dists, const float *noise, float noise_std, int R, int S,
                                         float *rgb_map, float *depth_map, float *rgb_map_fg,
                                         float *depth_map_fg, float *weights_fg, float *weights_dy,
                                         float *weights_dd_sum, void *stream) {
-    ZEST_CHECK_ARG(raw_dy && raw_st && blend && z && rays_dir,
-                   "zest_composite_blend_fwd: raw_dy, raw_st, blend, z, rays_dir are required");
+    ZEST_CHECK_ARG(raw_dy && raw_st && blend && z && (rays_dir || dists),
+                   "zest_composite_blend_fwd: raw_dy, raw_st, blend, z, rays_dir (or dists) are required");
     ZEST_CHECK_ARG(R >= 0 && S >= 1, "zest_composite_blend_fwd: bad shape R=%d S=%d", R, S);
     ZEST_CHECK_ARG((((uintptr_t)raw_dy | (uintptr_t)raw_st) & 15) == 0,
                    "zest_composite_blend_fwd: raw tensors must be 16-byte aligned");
     if (R == 0) return 0;
     hipLaunchKernelGGL(composite_blend_kernel, dim3(zest_div_up(R, kWavesPerBlock)),
                        dim3(kWavesPerBlock * ZEST_WAVE), 0, (hipStream_t)stream,
-                       (const float4 *)raw_dy, (const float4 *)raw_st, blend, z, rays_dir, noise,
+                       (const float4 *)raw_dy, (const float4 *)raw_st, blend, z, rays_dir, dists, noise,
                        noise_std, R, S, rgb_map, depth_map, rgb_map_fg, depth_map_fg, weights_fg,
                        weights_dy, weights_dd_sum);
     ZEST_RETURN_LAUNCH("zest_composite_blend_fwd");

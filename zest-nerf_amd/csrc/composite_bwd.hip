@@ -13,7 +13,9 @@ namespace {
 
 constexpr int kWaves = 4, kMaxChunks = 32;          // S <= 2048
 
-__device__ __forceinline__ float dist_of(const float *__restrict__ zr, int s, int S, float z, float dn) {
+__device__ __forceinline__ float dist_of(const float *__restrict__ zr, const float *__restrict__ dr, int s, int S,
+                                         float z, float dn) {
+    if (dr) return dr[s];                       // the caller's own spacings
     return ((s + 1 < S) ? (zr[s + 1] - z) : 1e10f) * dn;
 }
 
@@ -41,16 +43,19 @@ __device__ __forceinline__ float prefix_excl_prod(float f, int lane, float *tota
 
 __global__ __launch_bounds__(kWaves * 64) void composite_bwd_kernel(
     const float4 *__restrict__ raw, const float *__restrict__ z, const float *__restrict__ dir,
-    const float *__restrict__ noise, float noise_std, int white_bkgd, int R, int S,
+    const float *__restrict__ dists, const float *__restrict__ noise, float noise_std, int white_bkgd, int R, int S,
     const float *__restrict__ g_rgb, const float *__restrict__ g_depth, const float *__restrict__ g_acc,
     const float *__restrict__ g_w, float4 *__restrict__ g_raw) {
     __shared__ float carry_in[kWaves][kMaxChunks];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r = blockIdx.x * kWaves + wv;
     if (r >= R) return;
-    const float dx = dir[3 * r], dy = dir[3 * r + 1], dzv = dir[3 * r + 2];
-    const float dn = sqrtf(dx * dx + dy * dy + dzv * dzv);
-    const float *zr = z + (size_t)r * S;
+    float dn = 0.0f;
+    if (!dists) {
+        const float dx = dir[3 * r], dy = dir[3 * r + 1], dzv = dir[3 * r + 2];
+        dn = sqrtf(dx * dx + dy * dy + dzv * dzv);
+    }
+    const float *zr = z + (size_t)r * S, *dr = dists ? dists + (size_t)r * S : nullptr;
     const float gr = g_rgb ? g_rgb[3 * r] : 0.f, gg = g_rgb ? g_rgb[3 * r + 1] : 0.f,
                 gb = g_rgb ? g_rgb[3 * r + 2] : 0.f;
     const float gd = g_depth ? g_depth[r] : 0.f;
@@ -65,7 +70,7 @@ __global__ __launch_bounds__(kWaves * 64) void composite_bwd_kernel(
             float sig = raw[(size_t)r * S + s].w;
             if (noise) sig += noise[(size_t)r * S + s] * noise_std;
             const float zz = zr[s];
-            const float alpha = 1.0f - expf(-fmaxf(sig, 0.f) * dist_of(zr, s, S, zz, dn));
+            const float alpha = 1.0f - expf(-fmaxf(sig, 0.f) * dist_of(zr, dr, s, S, zz, dn));
             f = 1.0f - alpha + 1e-10f;
         }
         if (lane == 0) carry_in[wv][c] = carry;
@@ -84,7 +89,7 @@ __global__ __launch_bounds__(kWaves * 64) void composite_bwd_kernel(
             v = raw[(size_t)r * S + s];
             sigp = v.w + (noise ? noise[(size_t)r * S + s] * noise_std : 0.f);
             zz = zr[s];
-            dist = dist_of(zr, s, S, zz, dn);
+            dist = dist_of(zr, dr, s, S, zz, dn);
         }
         const float sig = fmaxf(sigp, 0.f);
         const float e = on ? expf(-sig * dist) : 1.0f;
@@ -109,7 +114,8 @@ __global__ __launch_bounds__(kWaves * 64) void composite_bwd_kernel(
 
 __global__ __launch_bounds__(kWaves * 64) void composite_blend_bwd_kernel(
     const float4 *__restrict__ raw_dy, const float4 *__restrict__ raw_st, const float *__restrict__ blend,
-    const float *__restrict__ z, const float *__restrict__ dir, const float *__restrict__ noise,
+    const float *__restrict__ z, const float *__restrict__ dir, const float *__restrict__ dists,
+    const float *__restrict__ noise,
     float noise_std, int R, int S, const float *__restrict__ g_rgb, const float *__restrict__ g_depth,
     const float *__restrict__ g_rgb_fg, const float *__restrict__ g_depth_fg,
     const float *__restrict__ g_wfg, const float *__restrict__ g_wd, float4 *__restrict__ g_raw_dy,
@@ -118,9 +124,12 @@ __global__ __launch_bounds__(kWaves * 64) void composite_blend_bwd_kernel(
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r = blockIdx.x * kWaves + wv;
     if (r >= R) return;
-    const float dx = dir[3 * r], dy = dir[3 * r + 1], dzv = dir[3 * r + 2];
-    const float dn = sqrtf(dx * dx + dy * dy + dzv * dzv);
-    const float *zr = z + (size_t)r * S;
+    float dn = 0.0f;
+    if (!dists) {
+        const float dx = dir[3 * r], dy = dir[3 * r + 1], dzv = dir[3 * r + 2];
+        dn = sqrtf(dx * dx + dy * dy + dzv * dzv);
+    }
+    const float *zr = z + (size_t)r * S, *dr = dists ? dists + (size_t)r * S : nullptr;
     float gm[3] = {0, 0, 0}, gf[3] = {0, 0, 0};
     if (g_rgb) gm[0] = g_rgb[3 * r], gm[1] = g_rgb[3 * r + 1], gm[2] = g_rgb[3 * r + 2];
     if (g_rgb_fg) gf[0] = g_rgb_fg[3 * r], gf[1] = g_rgb_fg[3 * r + 1], gf[2] = g_rgb_fg[3 * r + 2];
@@ -132,7 +141,7 @@ __global__ __launch_bounds__(kWaves * 64) void composite_blend_bwd_kernel(
         const size_t i = (size_t)r * S + s;
         vd = raw_dy[i], vs = raw_st[i], b = blend[i], zz = zr[s];
         const float n = noise ? noise[i] * noise_std : 0.f;
-        dist = dist_of(zr, s, S, zz, dn);
+        dist = dist_of(zr, dr, s, S, zz, dn);
         spd = vd.w + n, sps = vs.w + n;
         ed = expf(-fmaxf(spd, 0.f) * dist), es = expf(-fmaxf(sps, 0.f) * dist);
     };
@@ -204,35 +213,36 @@ __global__ __launch_bounds__(kWaves * 64) void composite_blend_bwd_kernel(
 
 }  // namespace
 
-extern "C" int zest_composite_bwd(const float *raw, const float *z, const float *rays_dir,
+extern "C" int zest_composite_bwd(const float *raw, const float *z, const float *rays_dir, const float *dists,
                                   const float *noise, float noise_std, int white_bkgd, int R, int S,
                                   const float *g_rgb_map, const float *g_depth_map, const float *g_acc_map,
                                   const float *g_weights, float *g_raw, void *stream) {
-    ZEST_CHECK_ARG(raw && z && rays_dir && g_raw, "zest_composite_bwd: raw, z, rays_dir, g_raw required");
+    ZEST_CHECK_ARG(raw && z && (rays_dir || dists) && g_raw, "zest_composite_bwd: raw, z, rays_dir (or dists), g_raw required");
     ZEST_CHECK_ARG(R >= 0 && S >= 1 && S <= 64 * kMaxChunks, "zest_composite_bwd: bad shape R=%d S=%d", R, S);
     ZEST_CHECK_ARG((((uintptr_t)raw | (uintptr_t)g_raw) & 15) == 0, "zest_composite_bwd: 16-byte alignment");
     if (R == 0) return 0;
     hipLaunchKernelGGL(composite_bwd_kernel, dim3(zest_div_up(R, kWaves)), dim3(kWaves * 64), 0,
-                       (hipStream_t)stream, (const float4 *)raw, z, rays_dir, noise, noise_std, white_bkgd, R,
+                       (hipStream_t)stream, (const float4 *)raw, z, rays_dir, dists, noise, noise_std, white_bkgd, R,
                        S, g_rgb_map, g_depth_map, g_acc_map, g_weights, (float4 *)g_raw);
     ZEST_RETURN_LAUNCH("zest_composite_bwd");
 }
 
 extern "C" int zest_composite_blend_bwd(const float *raw_dy, const float *raw_st, const float *blend,
-                                        const float *z, const float *rays_dir, const float *noise,
+                                        const float *z, const float *rays_dir, const float *dists,
+                                        const float *noise,
                                         float noise_std, int R, int S, const float *g_rgb_map,
                                         const float *g_depth_map, const float *g_rgb_map_fg,
                                         const float *g_depth_map_fg, const float *g_weights_fg,
                                         const float *g_weights_dy, float *g_raw_dy, float *g_raw_st,
                                         float *g_blend, void *stream) {
-    ZEST_CHECK_ARG(raw_dy && raw_st && blend && z && rays_dir && g_raw_dy && g_raw_st && g_blend,
+    ZEST_CHECK_ARG(raw_dy && raw_st && blend && z && (rays_dir || dists) && g_raw_dy && g_raw_st && g_blend,
                    "zest_composite_blend_bwd: null argument");
     ZEST_CHECK_ARG(R >= 0 && S >= 1 && S <= 64 * kMaxChunks, "zest_composite_blend_bwd: bad shape");
     ZEST_CHECK_ARG((((uintptr_t)raw_dy | (uintptr_t)raw_st | (uintptr_t)g_raw_dy | (uintptr_t)g_raw_st) & 15) == 0,
                    "zest_composite_blend_bwd: 16-byte alignment");
     if (R == 0) return 0;
     hipLaunchKernelGGL(composite_blend_bwd_kernel, dim3(zest_div_up(R, kWaves)), dim3(kWaves * 64), 0,
-                       (hipStream_t)stream, (const float4 *)raw_dy, (const float4 *)raw_st, blend, z, rays_dir,
+                       (hipStream_t)stream, (const float4 *)raw_dy, (const float4 *)raw_st, blend, z, rays_dir, dists,
                        noise, noise_std, R, S, g_rgb_map, g_depth_map, g_rgb_map_fg, g_depth_map_fg,
                        g_weights_fg, g_weights_dy, (float4 *)g_raw_dy, (float4 *)g_raw_st, g_blend);
     ZEST_RETURN_LAUNCH("zest_composite_blend_bwd");

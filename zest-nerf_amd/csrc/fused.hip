@@ -25,6 +25,7 @@ bool fill_net(const zest_mlp_desc *d, const void *packed, const zest_view_set *v
     memset(n, 0, sizeof(*n));
     if (!d || !packed) return *err = "descriptor and packed weights are required", false;
     if (d->in_ch_pts != pts_ch) return *err = "unexpected in_ch_pts for this slot", false;
+    if (d->net_type != 0 && d->net_type != 2) return *err = "net_type must be 0 ('v0') or 2 ('v2')", false;
     zest::MlpPlan plan;
     if (!zest::build_plan(*d, precision, zest::ORDER_ACC, &plan, err, false)) return false;
     n->bias = (const float *)packed;

@@ -117,7 +117,7 @@ struct F32Op {
 };
 struct F32Prog {
     F32Op op[zest::kNumOps];
-    int P, F, Vw, C_in, C_out, nt_feat, net_v2, head;
+    int P, F, Vw, C_in, C_out, nt_feat, net_v2, act_out, head;     // net_v2: additive modulation; act_out: sigmoid(rgb), relu(alpha)
     int rows_pts, rows_feat;   // padded row counts of the input buffers
 };
 
@@ -198,9 +198,9 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(F32Prog pr, const float
                     } else if (col < nvalid) {
                         float *orow = out + (size_t)(m0 + col) * pr.C_out;
                         if (o == 11) {                       // rgb tile
-                            if (row < 3) orow[row] = pr.net_v2 ? zest_sigmoid(v) : v;
+                            if (row < 3) orow[row] = pr.act_out ? zest_sigmoid(v) : v;
                         } else if (row == 0) {               // head tile: alpha
-                            orow[3] = pr.net_v2 ? fmaxf(v, 0.0f) : v;
+                            orow[3] = pr.act_out ? fmaxf(v, 0.0f) : v;
                         } else if (3 + row < pr.C_out) {     // blend weight | scene flow, prob
                             const bool is_sf = pr.head == ZEST_HEAD_DYNAMIC && row <= 6;
                             orow[3 + row] = is_sf ? tanhf(v) : zest_sigmoid(v);
@@ -230,7 +230,7 @@ F32Prog make_f32_prog(const MlpPlan &p) {
     pr.P = p.desc.in_ch_pts, pr.F = p.desc.use_feat ? p.desc.in_ch_feat : 0, pr.Vw = p.desc.in_ch_views;
     pr.C_in = pr.P + pr.F + pr.Vw;
     pr.C_out = p.desc.head == ZEST_HEAD_NONE ? 4 : (p.desc.head == ZEST_HEAD_BLEND ? 5 : 12);
-    pr.nt_feat = p.nt_feat, pr.net_v2 = p.desc.net_type == 2, pr.head = p.desc.head;
+    pr.nt_feat = p.nt_feat, pr.net_v2 = p.desc.net_type >= 2, pr.act_out = p.desc.net_type == 2, pr.head = p.desc.head;
     pr.rows_pts = p.nt_pts * 8, pr.rows_feat = p.nt_feat * 8;
     return pr;
 }

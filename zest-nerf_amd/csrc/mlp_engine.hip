@@ -67,7 +67,7 @@ constexpr int mlp_cb(int EP) { return EP == ZEST_PREC_F16X3 ? 1 : 2; }
 template <int EP, int NT_PTS, bool MOD, int NT_FEAT>
 __global__ __launch_bounds__(kMlpWaves * 64, kMlpWaves / 4) void mlp_engine_kernel(
     const uint4 *__restrict__ tiles_g, const float *__restrict__ x, int M, int P, int F, int C_in, int C_out, int head, int v2,
-    float *__restrict__ out) {
+    int act_out, float *__restrict__ out) {
     constexpr int NP = ep_parts(EP), CB = mlp_cb(EP), UNITS = stream_units(NT_PTS, MOD ? NT_FEAT : 0, NP);
     using Ring = RingTiles<kMlpWaves, UNITS, 0>;
     __shared__ __attribute__((aligned(16))) char lds[kRingUnits * 1024 + 2 * kSlots * 4];
@@ -121,10 +121,10 @@ __global__ __launch_bounds__(kMlpWaves * 64, kMlpWaves / 4) void mlp_engine_kern
             float *o = out + (size_t)m * C_out;
             // tile row r sits in lane group r >> 2, element r & 3
             if (grp == 0) {
-                o[0] = v2 ? zest_sigmoid(rgbt[cb][0]) : rgbt[cb][0];
-                o[1] = v2 ? zest_sigmoid(rgbt[cb][1]) : rgbt[cb][1];
-                o[2] = v2 ? zest_sigmoid(rgbt[cb][2]) : rgbt[cb][2];
-                o[3] = v2 ? fmaxf(headt[cb][0], 0.0f) : headt[cb][0];
+                o[0] = act_out ? zest_sigmoid(rgbt[cb][0]) : rgbt[cb][0];
+                o[1] = act_out ? zest_sigmoid(rgbt[cb][1]) : rgbt[cb][1];
+                o[2] = act_out ? zest_sigmoid(rgbt[cb][2]) : rgbt[cb][2];
+                o[3] = act_out ? fmaxf(headt[cb][0], 0.0f) : headt[cb][0];
                 if (head == ZEST_HEAD_BLEND) o[4] = zest_sigmoid(headt[cb][1]);
                 if (head == ZEST_HEAD_DYNAMIC)
                     o[4] = tanhf(headt[cb][1]), o[5] = tanhf(headt[cb][2]), o[6] = tanhf(headt[cb][3]);   // rows 1-3
@@ -160,7 +160,7 @@ static int launch_one(const MlpPlan &p, const void *tiles, const float *x, int M
     const int blocks = n_pass < cus ? n_pass : cus;             // one workgroup per CU (128 KiB ring)
     hipLaunchKernelGGL((mlp_engine_kernel<EP, NT_PTS, MOD, NT_FEAT>), dim3(blocks), dim3(kMlpWaves * 64), 0, stream,
                        (const uint4 *)tiles, x, M, d.in_ch_pts, F, C_in, C_out, d.head,
-                       d.net_type == 2 ? 1 : 0, out);
+                       d.net_type >= 2 ? 1 : 0, d.net_type == 2 ? 1 : 0, out);
     ZEST_RETURN_LAUNCH("zest_mlp_fwd(engine)");
 }
 

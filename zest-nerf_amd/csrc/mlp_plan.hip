@@ -84,8 +84,9 @@ bool build_plan(const zest_mlp_desc &d, int precision, int order, MlpPlan *P, co
     if (d.in_ch_views != 27) return *err = e_views, false;
     const int F = d.use_feat ? d.in_ch_feat : 0;
     if (d.use_feat && (F < 12 || (F - 8) % 4 != 0 || F > 72)) return *err = e_feat, false;
-    if (d.head < 0 || d.head > 2 || (d.net_type != 0 && d.net_type != 2) ||
-        (d.net_type == 2 && (d.head != 0 || !d.use_feat)))
+    // net_type 3: the 'v2' trunk (additive modulation) with raw outputs - Renderer_linear.forward_alpha
+    if (d.head < 0 || d.head > 2 || (d.net_type != 0 && d.net_type != 2 && d.net_type != 3) ||
+        (d.net_type >= 2 && (d.head != 0 || !d.use_feat)))
         return *err = e_head, false;
 
     MlpPlan &p = *P;

@@ -244,6 +244,7 @@ extern "C" size_t zest_mlp_train_workspace_floats(const zest_mlp_desc *desc, int
 extern "C" int zest_mlp_train_fwd(const zest_mlp_desc *desc, const float *const *params, const float *x,
                                   int M, float *saved, float *workspace, float *out, void *stream) {
     ZEST_CHECK_ARG(desc && params && x && saved && workspace && out && M > 0, "zest_mlp_train_fwd: bad argument");
+    ZEST_CHECK_ARG(desc->net_type == 0 || desc->net_type == 2, "zest_mlp_train_fwd: net_type must be 0 or 2");
     const Shape s = shape_of(*desc);
     hipStream_t st = (hipStream_t)stream;
     rocblas_handle h = handle_for(st);

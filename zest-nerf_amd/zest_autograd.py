@@ -70,9 +70,11 @@ class MlpFn(Function):
 
 class CompositeFn(Function):
     @staticmethod
-    def forward(ctx, raw, z, dirs, noise, noise_std, white_bkgd):
-        rgb, disp, acc, w, depth, alpha = zest_hip.composite(raw, z, dirs, noise, noise_std, white_bkgd)
-        ctx.cfg = (noise_std, white_bkgd)
+    def forward(ctx, raw, z, dirs, noise, noise_std, white_bkgd, is_dists=False):
+        sp = dict(rays_dir=None, dists=dirs) if is_dists else dict(rays_dir=dirs)
+        rgb, disp, acc, w, depth, alpha = zest_hip.composite(raw, z, noise=noise, noise_std=noise_std,
+                                                             white_bkgd=white_bkgd, **sp)
+        ctx.cfg = (noise_std, white_bkgd, is_dists)
         ctx.save_for_backward(raw, z, dirs, noise if noise is not None else raw.new_empty(0))
         ctx.mark_non_differentiable(disp, alpha)
         return rgb, disp, acc, w, depth, alpha
@@ -80,17 +82,20 @@ class CompositeFn(Function):
     @staticmethod
     def backward(ctx, g_rgb, g_disp, g_acc, g_w, g_depth, g_alpha):
         raw, z, dirs, noise = ctx.saved_tensors
-        g_raw = zest_hip.composite_bwd(raw, z, dirs, noise if noise.numel() else None, ctx.cfg[0], ctx.cfg[1],
-                                       g_rgb, g_depth, g_acc, g_w)
-        return g_raw, None, None, None, None, None
+        sp = dict(rays_dir=None, dists=dirs) if ctx.cfg[2] else dict(rays_dir=dirs)
+        g_raw = zest_hip.composite_bwd(raw, z, sp["rays_dir"], noise if noise.numel() else None, ctx.cfg[0],
+                                       ctx.cfg[1], g_rgb, g_depth, g_acc, g_w, dists=sp.get("dists"))
+        return g_raw, None, None, None, None, None, None
 
 
 class BlendFn(Function):
     @staticmethod
-    def forward(ctx, raw_dy, raw_st, blend, z, dirs, noise, noise_std):
-        rgb, depth, rgb_fg, depth_fg, w_fg, w_dy, dd = zest_hip.composite_blend(raw_dy, raw_st, blend, z, dirs,
-                                                                                noise, noise_std)
-        ctx.noise_std = noise_std
+    def forward(ctx, raw_dy, raw_st, blend, z, dirs, noise, noise_std, is_dists=False):
+        """dirs: rays_dir [R,3], or with is_dists the caller's own sample spacings [R,S]."""
+        sp = dict(rays_dir=None, dists=dirs) if is_dists else dict(rays_dir=dirs)
+        rgb, depth, rgb_fg, depth_fg, w_fg, w_dy, dd = zest_hip.composite_blend(raw_dy, raw_st, blend, z,
+                                                                                noise=noise, noise_std=noise_std, **sp)
+        ctx.noise_std, ctx.is_dists = noise_std, is_dists
         ctx.save_for_backward(raw_dy, raw_st, blend, z, dirs, noise if noise is not None else z.new_empty(0))
         ctx.mark_non_differentiable(dd)
         return rgb, depth, rgb_fg, depth_fg, w_fg, w_dy, dd
@@ -98,10 +103,11 @@ class BlendFn(Function):
     @staticmethod
     def backward(ctx, g_rgb, g_depth, g_rgb_fg, g_depth_fg, g_wfg, g_wd, g_dd):
         raw_dy, raw_st, blend, z, dirs, noise = ctx.saved_tensors
-        g_dy, g_st, g_b = zest_hip.composite_blend_bwd(raw_dy, raw_st, blend, z, dirs,
+        g_dy, g_st, g_b = zest_hip.composite_blend_bwd(raw_dy, raw_st, blend, z, None if ctx.is_dists else dirs,
                                                        noise if noise.numel() else None, ctx.noise_std, g_rgb,
-                                                       g_depth, g_rgb_fg, g_depth_fg, g_wfg, g_wd)
-        return g_dy, g_st, g_b, None, None, None, None
+                                                       g_depth, g_rgb_fg, g_depth_fg, g_wfg, g_wd,
+                                                       dists=dirs if ctx.is_dists else None)
+        return g_dy, g_st, g_b, None, None, None, None, None
 
 
 class Prob2dFn(Function):
@@ -116,11 +122,13 @@ class Prob2dFn(Function):
         return None, -(g[:, None] * w)
 
 
-def mlp_apply(net, x):
-    """Training forward of a zest networks.MVSNeRF on x [..., C_in] with autograd."""
+def mlp_apply(net, x, time_codes=None):
+    """Training forward of a zest networks.MVSNeRF on x [..., C_in] with autograd.  time_codes: the
+    frame's latent code for a net with time-code channels (folded into layer 0 / 5 biases with
+    differentiable torch ops: gradients reach the code and the full-width weights)."""
     mod = net.nerf
     desc = mod._desc()
-    named = dict(mod.named_parameters())
+    named = mod.effective_parameters(time_codes)
     slots, params = [], []
     for name, slot in zest_hip._PARAM_SLOTS:
         if name == "pts_bias" and not desc.use_feat:

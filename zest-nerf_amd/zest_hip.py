@@ -50,8 +50,8 @@ _SIGS = {
     "zest_abi_version": (_i, []),
     "zest_last_error": (C.c_char_p, []),
     "zest_device_info": (_i, [C.POINTER(_i), C.POINTER(_i), C.c_char_p, _sz]),
-    "zest_composite_fwd": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "zest_composite_blend_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i,
+    "zest_composite_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "zest_composite_blend_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i,
                                       _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "zest_weighted_complement_sum": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "zest_embed_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp]),
@@ -70,8 +70,8 @@ _SIGS = {
     "zest_build_rays_fwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i,
                                  _vp, _vp, _vp, _vp, _vp]),
     "zest_ndc_fwd": (_i, [_vp, _i, _vp, _vp, _f, _f, _f, _f, _i, _i, _vp, _vp]),
-    "zest_composite_bwd": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "zest_composite_blend_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+    "zest_composite_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "zest_composite_blend_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                       _vp, _vp, _vp, _vp]),
     "zest_encode_bwd": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "zest_volume_from_cl": (_i, [_vp, _i, _i, _i, _vp, _vp]),
@@ -142,26 +142,39 @@ def _dev(t, name):
 
 
 # ------------------------------------------------------------------------ compositing
-def composite(raw, z, rays_dir, noise=None, noise_std=0.0, white_bkgd=False, want_disp=True):
-    """raw [R,S,4], z [R,S], rays_dir [R,3] -> rgb_map, disp, acc, weights, depth, alpha."""
-    raw, z, rays_dir, noise = _dev(raw, "raw"), _dev(z, "z"), _dev(rays_dir, "rays_dir"), _dev(noise, "noise")
+def _spacing(z, rays_dir, dists):
+    """The sample spacing is either rebuilt in the kernel from z and |rays_dir| (depth2dist) or taken
+    from the caller's `dists` [R,S]."""
+    rays_dir, dists = _dev(rays_dir, "rays_dir"), _dev(dists, "dists")
+    if rays_dir is None and dists is None:
+        raise RuntimeError("zest_hip: compositing needs rays_dir or dists")
+    if dists is not None and tuple(dists.shape) != tuple(z.shape):
+        raise RuntimeError("zest_hip: dists %s does not match z %s" % (tuple(dists.shape), tuple(z.shape)))
+    return rays_dir, dists
+
+
+def composite(raw, z, rays_dir, noise=None, noise_std=0.0, white_bkgd=False, want_disp=True, dists=None):
+    """raw [R,S,4], z [R,S], rays_dir [R,3] (or dists [R,S]) -> rgb_map, disp, acc, weights, depth, alpha."""
+    raw, z, noise = _dev(raw, "raw"), _dev(z, "z"), _dev(noise, "noise")
+    rays_dir, dists = _spacing(z, rays_dir, dists)
     R, S = z.shape
     o = lambda *s: torch.empty(*s, device=z.device, dtype=torch.float32)
     rgb, depth, acc, disp, w, a = o(R, 3), o(R), o(R), o(R), o(R, S), o(R, S)
-    _check(lib().zest_composite_fwd(_ptr(raw), _ptr(z), _ptr(rays_dir), _ptr(noise), float(noise_std),
+    _check(lib().zest_composite_fwd(_ptr(raw), _ptr(z), _ptr(rays_dir), _ptr(dists), _ptr(noise), float(noise_std),
                                     int(bool(white_bkgd)), R, S, _ptr(rgb), _ptr(depth), _ptr(acc),
                                     _ptr(disp), _ptr(w), _ptr(a), _stream(z)), "zest_composite_fwd")
     return rgb, disp, acc, w, depth, a
 
 
-def composite_blend(raw_dy, raw_st, blend, z, rays_dir, noise=None, noise_std=0.0):
+def composite_blend(raw_dy, raw_st, blend, z, rays_dir, noise=None, noise_std=0.0, dists=None):
     raw_dy, raw_st, blend = _dev(raw_dy, "raw_dy"), _dev(raw_st, "raw_st"), _dev(blend, "blend")
-    z, rays_dir, noise = _dev(z, "z"), _dev(rays_dir, "rays_dir"), _dev(noise, "noise")
+    z, noise = _dev(z, "z"), _dev(noise, "noise")
+    rays_dir, dists = _spacing(z, rays_dir, dists)
     R, S = z.shape
     o = lambda *s: torch.empty(*s, device=z.device, dtype=torch.float32)
     rgb, depth, rgb_fg, depth_fg, w_fg, w_dy, dd = o(R, 3), o(R), o(R, 3), o(R), o(R, S), o(R, S), o(R)
     _check(lib().zest_composite_blend_fwd(_ptr(raw_dy), _ptr(raw_st), _ptr(blend), _ptr(z),
-                                          _ptr(rays_dir), _ptr(noise), float(noise_std), R, S,
+                                          _ptr(rays_dir), _ptr(dists), _ptr(noise), float(noise_std), R, S,
                                           _ptr(rgb), _ptr(depth), _ptr(rgb_fg), _ptr(depth_fg),
                                           _ptr(w_fg), _ptr(w_dy), _ptr(dd), _stream(z)),
            "zest_composite_blend_fwd")
@@ -366,27 +379,29 @@ def ndc_coordinate(pts, w2c, k, inv_w, inv_h, near, far, pad=0, lindisp=False):
     return out
 
 
-def composite_bwd(raw, z, rays_dir, noise, noise_std, white_bkgd, g_rgb, g_depth, g_acc, g_weights):
-    raw, z, rays_dir, noise = _dev(raw, "raw"), _dev(z, "z"), _dev(rays_dir, "rays_dir"), _dev(noise, "noise")
+def composite_bwd(raw, z, rays_dir, noise, noise_std, white_bkgd, g_rgb, g_depth, g_acc, g_weights, dists=None):
+    raw, z, noise = _dev(raw, "raw"), _dev(z, "z"), _dev(noise, "noise")
+    rays_dir, dists = _spacing(z, rays_dir, dists)
     gs = [_dev(g, "grad") for g in (g_rgb, g_depth, g_acc, g_weights)]
     R, S = z.shape
     g_raw = torch.empty(R, S, 4, device=z.device, dtype=torch.float32)
-    _check(lib().zest_composite_bwd(_ptr(raw), _ptr(z), _ptr(rays_dir), _ptr(noise), float(noise_std),
+    _check(lib().zest_composite_bwd(_ptr(raw), _ptr(z), _ptr(rays_dir), _ptr(dists), _ptr(noise), float(noise_std),
                                     int(bool(white_bkgd)), R, S, *[_ptr(g) for g in gs], _ptr(g_raw),
                                     _stream(z)), "zest_composite_bwd")
     return g_raw
 
 
 def composite_blend_bwd(raw_dy, raw_st, blend, z, rays_dir, noise, noise_std, g_rgb, g_depth, g_rgb_fg,
-                        g_depth_fg, g_wfg, g_wd):
+                        g_depth_fg, g_wfg, g_wd, dists=None):
     raw_dy, raw_st, blend = _dev(raw_dy, "raw_dy"), _dev(raw_st, "raw_st"), _dev(blend, "blend")
-    z, rays_dir, noise = _dev(z, "z"), _dev(rays_dir, "rays_dir"), _dev(noise, "noise")
+    z, noise = _dev(z, "z"), _dev(noise, "noise")
+    rays_dir, dists = _spacing(z, rays_dir, dists)
     gs = [_dev(g, "grad") for g in (g_rgb, g_depth, g_rgb_fg, g_depth_fg, g_wfg, g_wd)]
     R, S = z.shape
     o = lambda *s: torch.empty(*s, device=z.device, dtype=torch.float32)
     g_dy, g_st, g_b = o(R, S, 4), o(R, S, 4), o(R, S)
     _check(lib().zest_composite_blend_bwd(_ptr(raw_dy), _ptr(raw_st), _ptr(blend), _ptr(z), _ptr(rays_dir),
-                                          _ptr(noise), float(noise_std), R, S, *[_ptr(g) for g in gs],
+                                          _ptr(dists), _ptr(noise), float(noise_std), R, S, *[_ptr(g) for g in gs],
                                           _ptr(g_dy), _ptr(g_st), _ptr(g_b), _stream(z)),
            "zest_composite_blend_bwd")
     return g_dy, g_st, g_b

@@ -90,6 +90,14 @@ class _MlpBase(nn.Module):
                 "use_viewdirs=True (got D=%s W=%s skips=%s viewdirs=%s)" % (D, W, skips, use_viewdirs))
         self.D, self.W, self.skips, self.use_viewdirs = D, W, skips, use_viewdirs
         self.in_ch_pts, self.in_ch_views, self.in_ch_feat = input_ch, input_ch_views, input_ch_feat
+        # Encoded point = 63 (xyz) or 84 (xyzt) channels; anything beyond 63 that is not 84 is the
+        # Neural3D time code (reference train.py:112-113: input_ch += time_code_dim, static net).  The
+        # code is one vector per rendering call, the same for every sample, so its columns of layers 0
+        # and 5 fold into those layers' biases (effective_parameters) and the kernels see a 63-channel net.
+        self.in_ch_pe = input_ch if input_ch in (63, 84) else 63
+        self.in_ch_time = input_ch - self.in_ch_pe
+        if self.in_ch_time < 0:
+            raise NotImplementedError("zest MLP: input_ch=%d is smaller than the 63-channel point encoding" % input_ch)
         self.pts_linears = nn.ModuleList()
         for i in range(D - 1):
             if i == 0:
@@ -105,21 +113,75 @@ class _MlpBase(nn.Module):
     def _desc(self):
         raise NotImplementedError
 
-    def packed(self, precision):
-        """Weights in MFMA stream order; re-packed when any parameter changes (storage or version
-        counter: optimizer steps, load_state_dict and .to() all show up).  The (name, Parameter)
-        list is cached - walking the module tree costs more host time than a 1024-ray launch."""
+    def effective_parameters(self, time_codes=None):
+        """{name: tensor} of the 63/84-channel net the kernels run.  Without time-code channels these
+        are the parameters themselves.  With them (in_ch_time = T > 0) `time_codes` ([T] or [1,T], the
+        frame's latent code BEFORE the sigmoid, reference renderer.py:269-273) is folded in:
+            layer 0:  W0 [256, P+T]      -> W0[:, :P],               b0 + W0[:, P:] sigmoid(tc)
+            layer 5:  W5 [256, P+T+256]  -> W5[:, :P] | W5[:, P+T:],  b5 + W5[:, P:P+T] sigmoid(tc)
+        (the skip layer's input is [point | time code | h], networks.py:182).  Plain torch ops: under
+        autograd the gradients reach the original parameters and the code."""
+        params = self.__dict__.get("_zest_params")
+        if params is None:
+            params = self.__dict__["_zest_params"] = tuple(self.named_parameters())
+        named = dict(params)
+        T, P = self.in_ch_time, self.in_ch_pe
+        if T == 0:
+            if time_codes is not None:
+                raise RuntimeError("zest MLP: time_codes given to a net without time-code channels (input_ch=%d)" % P)
+            return named
+        if time_codes is None:
+            raise RuntimeError("zest MLP: this net has %d time-code input channels; pass time_codes to rendering()" % T)
+        tc = torch.sigmoid(time_codes.float()).reshape(-1)
+        if tc.numel() != T:
+            raise RuntimeError("zest MLP: time code has %d values, the net expects %d" % (tc.numel(), T))
+        w0, w5 = named["pts_linears.0.weight"], named["pts_linears.5.weight"]
+        named["pts_linears.0.weight"] = w0[:, :P].contiguous()
+        named["pts_linears.0.bias"] = named["pts_linears.0.bias"] + w0[:, P:] @ tc
+        named["pts_linears.5.weight"] = torch.cat([w5[:, :P], w5[:, P + T:]], 1)
+        named["pts_linears.5.bias"] = named["pts_linears.5.bias"] + w5[:, P:P + T] @ tc
+        return named
+
+    def packed(self, precision, desc=None, time_codes=None):
+        """Weights in MFMA stream order; re-packed when any parameter (or the time code) changes
+        (storage or version counter: optimizer steps, load_state_dict and .to() all show up).  The
+        (name, Parameter) list is cached - walking the module tree costs more host time than a
+        1024-ray launch.  desc: a variant descriptor of the same parameters (forward_alpha), packed and
+        cached apart."""
         params = self.__dict__.get("_zest_params")
         if params is None:
             params = self.__dict__["_zest_params"] = tuple(self.named_parameters())
         stamp = tuple((p.data_ptr(), p._version) for _, p in params)
-        hit = self._packed.get(precision)
+        if time_codes is not None:
+            stamp += ((time_codes.data_ptr(), time_codes._version),)
+        key = precision if desc is None else (precision, desc.use_feat, desc.net_type, desc.head)
+        hit = self._packed.get(key)
         if hit is None or hit[0] != stamp:
-            desc = self._desc()
-            state = {"nerf." + k: v.detach() for k, v in params}
+            desc = self._desc() if desc is None else desc
+            with torch.no_grad():
+                eff = self.effective_parameters(time_codes)
+            state = {"nerf." + k: v.detach() for k, v in eff.items()}
             hit = (stamp, zest_hip.mlp_pack(desc, precision, zest_hip.param_table(state, desc)))
-            self._packed[precision] = hit
+            self._packed[key] = hit
         return hit[1]
+
+    def _forward_alpha(self, x, net_type, relu):
+        """Density-only pass of the reference (networks.py:134-147, 266-280): x = [points | features]
+        (no direction columns), the trunk ALWAYS modulated by pts_bias(features).  Runs the MLP kernel
+        with zero direction columns and the alpha head, and keeps the density column."""
+        if self.in_ch_time:
+            raise NotImplementedError("forward_alpha: not available for nets with time-code channels")
+        if x.shape[-1] != self.in_ch_pts + self.in_ch_feat:
+            raise RuntimeError("forward_alpha expects %d + %d input channels, got %d"
+                               % (self.in_ch_pts, self.in_ch_feat, x.shape[-1]))
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("forward_alpha: inference only (the reference never calls it: "
+                                      "renderer.py:295 sets alpha_only only when no direction is given)")
+        desc = zest_hip.MlpDesc(self.in_ch_pts, self.in_ch_feat, self.in_ch_views, 1, net_type, zest_hip.HEAD_NONE)
+        prec = inference_precision(resolve_precision())
+        xin = torch.cat([x, x.new_zeros(*x.shape[:-1], self.in_ch_views)], -1)
+        alpha = zest_hip.mlp_fwd(desc, prec, self.packed(prec, desc), xin)[..., 3:4]
+        return torch.relu(alpha) if relu else alpha
 
     def __setattr__(self, name, value):
         if isinstance(value, (nn.Parameter, nn.Module)):
@@ -130,6 +192,9 @@ class _MlpBase(nn.Module):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             raise RuntimeError("zest MLP: use MVSNeRF.forward (it owns the `nerf.` parameter names the "
                                "training path needs)")
+        if self.in_ch_time:
+            raise NotImplementedError("zest MLP: a net with time-code channels runs through rendering(..., time_codes=...), "
+                                      "which folds the frame's code into the biases of layers 0 and 5")
         desc = self._desc()
         prec = inference_precision(resolve_precision()) if precision is None else precision
         return zest_hip.mlp_fwd(desc, prec, self.packed(prec), x)
@@ -157,12 +222,12 @@ class Renderer(_MlpBase):
         head = zest_hip.HEAD_NONE
         if self.predict_sceneflow:
             head = zest_hip.HEAD_BLEND if self.static else zest_hip.HEAD_DYNAMIC
-        return zest_hip.MlpDesc(self.in_ch_pts, self.in_ch_feat, self.in_ch_views,
+        return zest_hip.MlpDesc(self.in_ch_pe, self.in_ch_feat, self.in_ch_views,
                                 int(bool(self.use_mvs)), 0, head)
 
     def forward_alpha(self, x):
-        raise NotImplementedError("forward_alpha is dead code in the reference "
-                                  "(renderer.py:295 never sets alpha_only); not implemented")
+        """relu(alpha_linear(trunk(x))) with multiplicative modulation (reference networks.py:134-147)."""
+        return self._forward_alpha(x, 0, True)
 
 
 class Renderer_linear(_MlpBase):
@@ -174,11 +239,12 @@ class Renderer_linear(_MlpBase):
         self._build(D, W, input_ch, input_ch_views, input_ch_feat, skips, use_viewdirs)
 
     def _desc(self):
-        return zest_hip.MlpDesc(self.in_ch_pts, self.in_ch_feat, self.in_ch_views, 1, 2,
+        return zest_hip.MlpDesc(self.in_ch_pe, self.in_ch_feat, self.in_ch_views, 1, 2,
                                 zest_hip.HEAD_NONE)
 
     def forward_alpha(self, x):
-        raise NotImplementedError("forward_alpha is dead code in the reference; not implemented")
+        """alpha_linear(trunk(x)), additive modulation, no activation (reference networks.py:266-280)."""
+        return self._forward_alpha(x, 3, False)
 
 
 class MVSNeRF(nn.Module):
@@ -205,8 +271,8 @@ class MVSNeRF(nn.Module):
     def desc(self):
         return self.nerf._desc()
 
-    def packed(self, precision):
-        return self.nerf.packed(precision)
+    def packed(self, precision, time_codes=None):
+        return self.nerf.packed(precision, time_codes=time_codes)
 
     def forward_alpha(self, x):
         return self.nerf.forward_alpha(x)
@@ -215,7 +281,8 @@ class MVSNeRF(nn.Module):
         return self.nerf.zest_forward(x, precision)
 
     def forward(self, x):
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+        if self.nerf.in_ch_time == 0 and torch.is_grad_enabled() and (
+                x.requires_grad or any(p.requires_grad for p in self.parameters())):
             import zest_autograd
             return zest_autograd.mlp_apply(self, x)          # fp32 training path (HIP fwd + bwd)
         return self.nerf(x)
@@ -229,9 +296,10 @@ class MVSNeRF(nn.Module):
 # InPlaceABN (inplace_abn, a CUDA-only extension that is not installable here): its forward is
 # batch norm followed by leaky ReLU(0.01), and its parameters are weight / bias / running_mean /
 # running_var, so ActivatedBatchNorm keeps the reference's state-dict keys and checkpoints load.
-# Parity: the plane sweep is pinned by reference-generated fixtures (tests/golden/volume_cost*,
-# homo_warp*); the convolutional stacks cannot be run in the reference without inplace_abn and
-# are "parity unpinned" (DESIGN.md 4b).
+# Parity: the sampling half of homo_warp is pinned by a reference-generated fixture
+# (tests/golden/homo_warp.npz); the grid construction and build_volume_cost are checked against the
+# oracle's restatement of the source text, and the convolutional stacks cannot be run in the
+# reference without inplace_abn: "parity unpinned" for those.
 class ActivatedBatchNorm(nn.BatchNorm2d):
     """InPlaceABN substitute: BatchNorm (any spatial rank) + leaky ReLU(0.01)."""
 

@@ -51,68 +51,57 @@ def compute_2d_prob(weights_p_mix, raw_prob_ref2p):
 
 def depth2dist(z_vals, cos_angle):
     """Sample spacing along the ray, last = 1e10, scaled by |dir| (reference renderer.py:74-89).
-    Kept for API parity; the compositing kernels recompute this from z and rays_dir."""
+    For callers of the module-level raw2outputs*; `rendering` itself lets the compositing kernels
+    rebuild the spacing from z and rays_dir."""
     d = z_vals[..., 1:] - z_vals[..., :-1]
     d = torch.cat([d, torch.full_like(z_vals[..., :1], 1e10)], -1)
     return d * cos_angle
 
 
-def _split_dists(z_vals, dists):
-    """The kernels take (z, |dir|); recover |dir| from the caller's dists = dz * |dir|."""
-    z = z_vals.reshape(-1, z_vals.shape[-1])
-    d = dists.reshape(-1, dists.shape[-1])
-    norm = d[:, -1:] / 1e10
-    pseudo_dir = torch.cat([torch.zeros_like(norm), torch.zeros_like(norm), norm], -1)
-    return z, pseudo_dir
-
-
 def raw2alpha(sigma, dist):
     """alpha = 1 - exp(-sigma*dist), weights = alpha * exclusive-prod(1 - alpha + 1e-10)
-    (reference renderer.py:91-113).  Runs the compositing kernel on depths rebuilt from the
-    spacings; sigma < 0 is clamped to 0, which every reference caller has already done."""
+    (reference renderer.py:91-113), on the compositing kernel with the caller's spacings; sigma < 0
+    is clamped to 0, which every reference caller has already done."""
     _no_grad_only(sigma, dist)
     lead, S = sigma.shape[:-1], sigma.shape[-1]
     d = dist.reshape(-1, S).float()
-    norm = d[:, -1:] / 1e10
-    z = torch.cumsum(torch.cat([torch.zeros_like(norm), d[:, :-1] / norm], -1), -1)
     raw = torch.zeros(d.shape[0], S, 4, device=d.device)
     raw[..., 3] = sigma.reshape(-1, S)
-    pdir = torch.cat([torch.zeros_like(norm), torch.zeros_like(norm), norm], -1)
-    _, _, _, w, _, a = zest_hip.composite(raw, z, pdir)
+    _, _, _, w, _, a = zest_hip.composite(raw, torch.zeros_like(d), None, dists=d)
     return a.view(*lead, S), w.view(*lead, S)
 
 
 def raw2outputs(raw, z_vals, dists, white_bkgd=False, raw_noise_std=0):
     """[N,R,S,4] -> rgb_map, disp_map, acc_map, weights, depth_map, alpha
-    (reference renderer.py:115-164)."""
+    (reference renderer.py:115-164).  `dists` is used as given, whatever produced it."""
     lead, S = z_vals.shape[:-1], z_vals.shape[-1]
-    z, pdir = _split_dists(z_vals, dists)
+    z, d = z_vals.reshape(-1, S), dists.reshape(-1, S)
     noise = _draw_noise(z_vals.shape, z_vals.device).reshape(-1, S) if raw_noise_std > 0 else None
     if torch.is_grad_enabled() and raw.requires_grad:
         import zest_autograd as za
-        rgb, disp, acc, w, depth, a = za.CompositeFn.apply(raw.reshape(-1, S, 4).contiguous(), z, pdir, noise,
-                                                           float(raw_noise_std), bool(white_bkgd))
+        rgb, disp, acc, w, depth, a = za.CompositeFn.apply(raw.reshape(-1, S, 4).contiguous(), z, d.contiguous(), noise,
+                                                           float(raw_noise_std), bool(white_bkgd), True)
     else:
-        rgb, disp, acc, w, depth, a = zest_hip.composite(raw.reshape(-1, S, 4), z, pdir, noise,
-                                                         float(raw_noise_std), bool(white_bkgd))
+        rgb, disp, acc, w, depth, a = zest_hip.composite(raw.reshape(-1, S, 4), z, None, noise,
+                                                         float(raw_noise_std), bool(white_bkgd), dists=d)
     return (rgb.view(*lead, 3), disp.view(*lead), acc.view(*lead), w.view(*lead, S),
             depth.view(*lead), a.view(*lead, S))
 
 
 def raw2outputs_blending(raw_dy, raw_rigid, raw_blend_w, z_vals, dists, raw_noise_std=0):
     """-> rgb_map, depth_map, rgb_map_fg, depth_map_fg, weights_fg, weights_dy
-    (reference renderer.py:166-219)."""
+    (reference renderer.py:166-219).  `dists` is used as given."""
     lead, S = z_vals.shape[:-1], z_vals.shape[-1]
-    z, pdir = _split_dists(z_vals, dists)
+    z, d = z_vals.reshape(-1, S), dists.reshape(-1, S)
     noise = _draw_noise(z_vals.shape, z_vals.device).reshape(-1, S) if raw_noise_std > 0 else None
     args3 = (raw_dy.reshape(-1, S, 4), raw_rigid.reshape(-1, S, 4), raw_blend_w.reshape(-1, S))
     if torch.is_grad_enabled() and any(t.requires_grad for t in args3):
         import zest_autograd as za
         rgb, depth, rgb_fg, depth_fg, w_fg, w_dy, _ = za.BlendFn.apply(
-            *[t.contiguous() for t in args3], z, pdir, noise, float(raw_noise_std))
+            *[t.contiguous() for t in args3], z, d.contiguous(), noise, float(raw_noise_std), True)
     else:
-        rgb, depth, rgb_fg, depth_fg, w_fg, w_dy, _ = zest_hip.composite_blend(*args3, z, pdir, noise,
-                                                                               float(raw_noise_std))
+        rgb, depth, rgb_fg, depth_fg, w_fg, w_dy, _ = zest_hip.composite_blend(*args3, z, None, noise,
+                                                                               float(raw_noise_std), dists=d)
     return (rgb.view(*lead, 3), depth.view(*lead), rgb_fg.view(*lead, 3), depth_fg.view(*lead),
             w_fg.view(*lead, S), w_dy.view(*lead, S))
 
@@ -153,7 +142,7 @@ def _net(network_fn, what):
     return network_fn
 
 
-def _render_maps_fused(prec, rays_ndc, ndc, pts, z, dirs, net_s, network_fn_dy, scene_flow, vol_s, vol_d,
+def _render_maps_fused(prec, time_codes, rays_ndc, ndc, pts, z, dirs, net_s, network_fn_dy, scene_flow, vol_s, vol_d,
                        imgs, nb_imgs, cam, nb_cam, embedding_xyzt, embedding_dir, ref_frame_idx,
                        white_bkgd, raw_noise_std):
     """Per-ray maps only, one kernel launch (zest_render_fused_fwd).  Returns the per-ray keys
@@ -169,7 +158,7 @@ def _render_maps_fused(prec, rays_ndc, ndc, pts, z, dirs, net_s, network_fn_dy, 
         vd = _Views(vol_d, nb_imgs, nb_cam)
         desc_d, packed_d = net_d.desc(), net_d.packed(prec)
         views_d = zest_hip.make_view_set(vd.vol_cl, vd.imgs_cl, vd.w2cs, vd.intr)
-    out = zest_hip.render_fused(ndc, pts, z, dirs, net_s.desc(), net_s.packed(prec),
+    out = zest_hip.render_fused(ndc, pts, z, dirs, net_s.desc(), net_s.packed(prec, time_codes),
                                 views_s, desc_d, packed_d, views_d,
                                 ref_frame_idx if scene_flow else 0.0, white_bkgd, precision=prec)
     ret = {'rgb_map': out[None, :, 0:3], 'depth_map': out[None, :, 3], 'acc_map': out[None, :, 4],
@@ -194,8 +183,6 @@ def rendering(args, rays_pts, rays_ndc, depth_candidates, rays_dir,
     """Volume-render a batch of rays; same arguments and result keys as the reference
     (renderer.py:579-626).  rays_pts/rays_ndc [1,R,S,3], depth_candidates [1,R,S],
     rays_dir [1,R,3]."""
-    if time_codes is not None:
-        raise NotImplementedError("zest renderer: time codes (Neural3D video mode) are out of scope")
     if img_feat is not None:
         raise NotImplementedError("zest renderer: img_feat is always None in the reference callers")
     if getattr(args, "use_color_volume", False):
@@ -212,8 +199,10 @@ def rendering(args, rays_pts, rays_ndc, depth_candidates, rays_dir,
     # then runs as an autograd.Function with HIP forward and backward (zest_autograd.py), fp32.
     def wants_grad(*ts):
         return any(t is not None and torch.is_tensor(t) and t.requires_grad for t in ts)
+    # Neural3D time code (reference renderer.py:269-273; static net only, :351): constant over the
+    # batch, so the net folds it into the biases of its layers 0 and 5 (zest_networks.effective_parameters)
     train = torch.is_grad_enabled() and (
-        wants_grad(rays_ndc, volume_feature_static, volume_feature_dynamic)
+        wants_grad(rays_ndc, volume_feature_static, volume_feature_dynamic, time_codes)
         or any(p.requires_grad for p in net_s.parameters())
         or (network_fn_dy is not None and any(p.requires_grad for p in network_fn_dy.parameters())))
     if train:
@@ -224,17 +213,17 @@ def rendering(args, rays_pts, rays_ndc, depth_candidates, rays_dir,
     # complete plan below, whose stages have backward kernels.
     if getattr(args, "zest_maps_only", False) and (val or not scene_flow) and not train:
         fused_prec = zest_hip.PREC_F16X3 if prec == zest_hip.PREC_F32 else prec     # no exact-product fused kernel
-        return _render_maps_fused(fused_prec, rays_ndc, ndc, pts, z, dirs, net_s, network_fn_dy, scene_flow,
+        return _render_maps_fused(fused_prec, time_codes, rays_ndc, ndc, pts, z, dirs, net_s, network_fn_dy, scene_flow,
                                   volume_feature_static, volume_feature_dynamic, imgs,
                                   neighbour_frames, im_cam_mat, nb_cam_mat, embedding_xyzt,
                                   embedding_dir, ref_frame_idx, white_bkgd, raw_noise_std)
 
     mlp_prec = inference_precision(prec, args)
 
-    def mlp(net, x):
+    def mlp(net, x, tc=None):
         if train:
-            return za.mlp_apply(net, x)
-        return zest_hip.mlp_fwd(net.desc(), mlp_prec, net.packed(mlp_prec), x)
+            return za.mlp_apply(net, x, tc)
+        return zest_hip.mlp_fwd(net.desc(), mlp_prec, net.packed(mlp_prec, tc), x)
 
     def encode(views, volume, ndc3, t=None):
         if train:
@@ -254,7 +243,7 @@ def rendering(args, rays_pts, rays_ndc, depth_candidates, rays_dir,
     if train and rays_ndc.requires_grad:
         ndc = rays_ndc[0].float()
     x_s = encode(vs, volume_feature_static, ndc)
-    raw_s = mlp(net_s, x_s)
+    raw_s = mlp(net_s, x_s, time_codes)
     raw_rgba = raw_s[..., :4]
     blend = raw_s[..., 4] if scene_flow else None
     rgb_map, _, _, weights, depth_map, alpha = composite(raw_rgba, noise(), raw_noise_std, white_bkgd)

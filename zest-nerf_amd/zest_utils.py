@@ -21,15 +21,21 @@ _CL_CACHE_MAX = 8
 
 
 def _cached(kind, t, make):
-    key = (kind, t.data_ptr(), tuple(t.shape), t._version, str(t.device))
+    """Channels-last copy of `t`, made once per (memory, layout, content version).  The key is the
+    view's address, shape, strides and version counter; the entry holds a weak reference to the tensor
+    that OWNS the memory (`t._base` for a view), so a fresh view of the same live tensor - the
+    generators pass `imgs[:, :-1]` anew for each of the ~144 chunks of an image - hits, and memory that
+    was freed and handed out again does not (its owner is gone)."""
+    owner = t._base if t._base is not None else t
+    key = (kind, t.data_ptr(), tuple(t.shape), tuple(t.stride()), t._version, str(t.device))
     hit = _CL_CACHE.get(key)
-    if hit is not None and hit[0]() is t:
+    if hit is not None and hit[0]() is owner:
         return hit[1]
     out = make(t)
     if len(_CL_CACHE) >= _CL_CACHE_MAX:
         _CL_CACHE.pop(next(iter(_CL_CACHE)))
     try:
-        _CL_CACHE[key] = (weakref.ref(t), out)
+        _CL_CACHE[key] = (weakref.ref(owner), out)
     except TypeError:
         pass
     return out

@@ -137,6 +137,20 @@ int zest_homo_warp_fwd(const float *src, const float *proj, const float *depth, 
                        int C, int D, int H, int W, int Hp, int Wp, int pad, float *warped,
                        float *grid_out, void *stream);
 
+/* Backward of the plane sweep (the MVSNet trains through it: reference train.py:270 optimises
+ * generator.parameters(), networks.py:1077-1140 runs under autograd).  The trainable input is the
+ * feature maps; images, homographies, depths and the in-frame counts carry no gradient.
+ * zest_volume_cost_bwd: g_img_feat [3V+32, D, Hp, Wp] (gradient of zest_volume_cost_fwd's img_feat;
+ *   only the 32 variance channels are read) -> g_feats_cl [V,H,W,32], ACCUMULATED with float atomics
+ *   (zero it first).  The warped features are gathered again from feats_cl, not stored.
+ * zest_homo_warp_bwd: g_warped [C,D,Hp,Wp] -> g_src [C,H,W], accumulated (zero it first); grid_in or
+ *   proj + depth as in the forward call. */
+int zest_volume_cost_bwd(const float *feats_cl, const float *proj, const float *depth, int V, int C,
+                         int D, int H, int W, int pad, const float *g_img_feat, float *g_feats_cl,
+                         void *stream);
+int zest_homo_warp_bwd(const float *proj, const float *depth, const float *grid_in, int C, int D, int H,
+                       int W, int Hp, int Wp, int pad, const float *g_warped, float *g_src, void *stream);
+
 /* ---- loss-side reductions over the samples of a ray -------------------
  * zest_distortion_fwd: distortion_loss (reference losses.py:53-87) per ray.  weights [R,S];
  *   t_vals [t_rows,S] with t_rows 1 or R.  loss_ray [R] (the reference returns their sum);

@@ -111,14 +111,15 @@ def _batch(seed, H=32, W=32, V=3, V_dy=3):     # MVSNet's regulariser takes 3 vi
                 nb_proj_mats=G(cost_dy["proj_mats"]), nb_w2cs=G(nb_w2cs), nb_intr=G(nb_intr))
 
 
-def _generator(args):
+def _generator(args, train_builders=False):
     import zest_networks as networks
     import golden_cases as gc
     torch.manual_seed(1)
     mk = lambda P, F, static: networks.MVSNeRF(D=8, W=256, input_ch_pts=P, output_ch=4, input_ch_views=gc.PE_DIR,
                                                input_ch_feat=F, skips=[4], net_type="v0", sceneflow=True,
                                                static=static, use_mvs=True).cuda()
-    enc, enc_dy = networks.MVSNet().cuda().requires_grad_(False), networks.MVSNet().cuda().requires_grad_(False)
+    enc, enc_dy = (networks.MVSNet().cuda().requires_grad_(train_builders),
+                   networks.MVSNet().cuda().requires_grad_(train_builders))
     return networks.DyMVSNeRF_G(args, 1, mk(gc.PE_XYZT, 20, False), mk(gc.PE_PTS, 20, True), enc, enc_dy,
                                 networks.Embedding(3, 10), networks.Embedding(4, 10), networks.Embedding(3, 4))
 
@@ -155,3 +156,20 @@ def test_training_forward_returns_the_reference_keys(hip):
     loss.backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in gen.nerf_static.parameters())
     assert all(p.grad is None for p in gen.encoding_net.parameters())      # frozen volume builder
+
+
+@pytest.mark.gpu
+def test_training_step_reaches_the_volume_builders(hip):
+    """The reference optimises generator.parameters() INCLUDING both MVSNets (train.py:270): with trainable
+    builders a training forward + backward leaves finite, non-zero gradients on FeatureNet and CostRegNet of
+    the static and of the dynamic builder (rendering -> encode backward -> 3-D CNN -> HIP plane-sweep
+    backward -> 2-D CNN)."""
+    x = _batch(93)
+    gen = _generator(_args(), train_builders=True)
+    ret = gen(x, step=0)
+    loss = ret["rgb_map_ref"].square().mean() + ret["rgb_map"].square().mean() + ret["rgb_map_ref_dy"].square().mean()
+    loss.backward()
+    for enc in (gen.encoding_net, gen.encoding_net_dy):
+        grads = {k: p.grad for k, p in enc.named_parameters()}
+        assert all(g is not None and torch.isfinite(g).all() for g in grads.values())
+        assert grads["feature.conv0.0.conv.weight"].abs().max() > 0 and grads["cost_reg_2.conv0.conv.weight"].abs().max() > 0

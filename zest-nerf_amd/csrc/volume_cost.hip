@@ -243,6 +243,124 @@ __global__ __launch_bounds__(kThreads) void homo_warp_kernel(
     }
 }
 
+// ---- backward of the plane sweep ----------------------------------------------------------
+// The trainable input of build_volume_cost is the feature maps (FeatureNet's output; the images,
+// homographies and depths are data, and the in-frame counts come from comparisons: no gradient).
+// Per voxel and channel, with a_i the (warped) feature of view i, n the in-frame count and
+// var = sum a_i^2 / n - (sum a_i / n)^2:      d var / d a_i = (2 / n) (a_i - mean).
+// The warped features are not kept by the forward pass (V-1 volumes of 350 MB each at the NSFF
+// geometry): they are gathered again here.  A workgroup is one wave and owns 64 consecutive voxels,
+// as in the forward kernel: phase 1 (lane = voxel) recomputes the homographies and bilinear taps
+// into LDS and transposes the 32 gradient planes of its voxels through LDS (each plane read as 256
+// contiguous bytes); phase 2 walks the voxels two at a time with lane = (voxel of the pair,
+// channel): a bilinear tap is one 128-byte line per voxel, read - and scattered back with float
+// atomics - by 32 neighbouring lanes, the access shape at which memory-side float atomics run at
+// full rate (MI355X_MICROARCH.md, Global float atomics: two 128-B segments per wave-instruction).
+// feats_cl [V,H,W,32], g_img_feat [3V+32, D, Hp, Wp] (only its last 32 channels are read),
+// g_feats_cl [V,H,W,32] accumulated (zero it first).
+template <int VT>
+__global__ __launch_bounds__(64) void volume_cost_bwd_kernel(
+    const float *__restrict__ feats, const float *__restrict__ proj, const float *__restrict__ depth, int V_rt,
+    int D, int H, int W, int pad, const float *__restrict__ g_img_feat, float *__restrict__ g_feats) {
+    const int V = VT > 0 ? VT : V_rt;
+    constexpr int VM = VT > 0 ? VT : kMaxViews;
+    __shared__ float gt[kC * kRowStride];                      // gradient of the variance planes [channel][voxel]
+    __shared__ int4 toff[(VM - 1) * 64];
+    __shared__ float4 tw[(VM - 1) * 64];
+    __shared__ float2 vox[64];                                  // ref pixel offset (-1: none), 1/count
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+    const long long nvox = (long long)D * Hp * Wp;
+    const int lane = threadIdx.x;
+    const long long base = (long long)blockIdx.x * 64;
+    {   // ---- phase 1: lane = voxel
+        const long long idx = base + lane;
+        const bool live = idx < nvox;
+        const unsigned ic = (unsigned)(live ? idx : nvox - 1);
+        const unsigned row = ic / (unsigned)Wp;
+        const int x = (int)(ic - row * (unsigned)Wp), d = (int)(row / (unsigned)Hp), y = (int)(row - (unsigned)d * (unsigned)Hp);
+        const int xr = x - pad, yr = y - pad;
+        const bool inside = (unsigned)xr < (unsigned)W && (unsigned)yr < (unsigned)H;
+        const float dep = depth[d];
+        float count = 1.0f;
+#pragma unroll
+        for (int i = 1; i < V; i++) {
+            float gx, gy;
+            project(proj + 12 * (i - 1), (float)xr, (float)yr, dep, H, W, gx, gy);
+            count += (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.0f : 0.0f;
+            const Tap4 t = taps(gx, gy, H, W);
+            toff[(i - 1) * 64 + lane] = make_int4(t.off[0], t.off[1], t.off[2], t.off[3]);
+            // a voxel past the end of the volume scatters nothing
+            tw[(i - 1) * 64 + lane] = live ? make_float4(t.w[0], t.w[1], t.w[2], t.w[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        vox[lane] = make_float2(__int_as_float(live && inside ? yr * W + xr : -1), 1.0f / count);
+        const size_t plane0 = (size_t)(3 * V) * nvox;
+        for (int c = 0; c < kC; c++)
+            gt[c * kRowStride + lane] = live ? g_img_feat[plane0 + (size_t)c * nvox + idx] : 0.0f;
+    }
+    __syncthreads();
+    // ---- phase 2: lane = (voxel of a pair, channel)
+    const int c = lane & 31, vp = lane >> 5;
+    const size_t HW = (size_t)H * W;
+    for (int it = 0; it < 32; it++) {
+        const int v = 2 * it + vp;
+        const float2 gv = vox[v];
+        const int ref_off = __float_as_int(gv.x);
+        const float g = gt[c * kRowStride + v], inv = gv.y;
+        float a[VM];
+        a[0] = ref_off >= 0 ? feats[(size_t)ref_off * kC + c] : 0.0f;
+        float sum = a[0];
+#pragma unroll
+        for (int i = 1; i < V; i++) {
+            const int4 o4 = toff[(i - 1) * 64 + v];
+            const float4 w4 = tw[(i - 1) * 64 + v];
+            const float *f = feats + (size_t)i * HW * kC + c;
+            a[i] = fmaf(w4.w, f[(size_t)o4.w * kC], fmaf(w4.z, f[(size_t)o4.z * kC],
+                        fmaf(w4.y, f[(size_t)o4.y * kC], w4.x * f[(size_t)o4.x * kC])));
+            sum += a[i];
+        }
+        const float mean = sum * inv, k = 2.0f * inv * g;
+        if (ref_off >= 0) atomicAdd(g_feats + (size_t)ref_off * kC + c, k * (a[0] - mean));
+#pragma unroll
+        for (int i = 1; i < V; i++) {
+            const int4 o4 = toff[(i - 1) * 64 + v];
+            const float4 w4 = tw[(i - 1) * 64 + v];
+            float *gf = g_feats + (size_t)i * HW * kC + c;
+            const float ga = k * (a[i] - mean);
+            // wave-uniform per half: a tap with weight 0 (outside the frame) is skipped by all 32 lanes
+            if (w4.x != 0.0f) atomicAdd(gf + (size_t)o4.x * kC, w4.x * ga);
+            if (w4.y != 0.0f) atomicAdd(gf + (size_t)o4.y * kC, w4.y * ga);
+            if (w4.z != 0.0f) atomicAdd(gf + (size_t)o4.z * kC, w4.z * ga);
+            if (w4.w != 0.0f) atomicAdd(gf + (size_t)o4.w * kC, w4.w * ga);
+        }
+    }
+}
+
+// backward of homo_warp with respect to the source map: g_warped [C,D,Hp,Wp] -> g_src [C,H,W]
+// (accumulated: zero it first).  The sampling positions (grid or homography + depths) are data.
+__global__ __launch_bounds__(kThreads) void homo_warp_bwd_kernel(
+    const float *__restrict__ proj, const float *__restrict__ depth, const float *__restrict__ grid_in, int C, int D,
+    int H, int W, int Hp, int Wp, int pad, const float *__restrict__ g_warped, float *__restrict__ g_src) {
+    const long long nvox = (long long)D * Hp * Wp;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nvox) return;
+    float gx, gy;
+    if (grid_in) {
+        gx = grid_in[2 * idx], gy = grid_in[2 * idx + 1];
+    } else {
+        const unsigned row = (unsigned)idx / (unsigned)Wp;
+        const int x = (int)((unsigned)idx - row * (unsigned)Wp), d = (int)(row / (unsigned)Hp), y = (int)(row - (unsigned)d * (unsigned)Hp);
+        project(proj, (float)(x - pad), (float)(y - pad), depth[d], H, W, gx, gy);
+    }
+    const Tap4 t = taps(gx, gy, H, W);
+    for (int c = 0; c < C; c++) {
+        const float g = g_warped[(size_t)c * nvox + idx];
+        float *s = g_src + (size_t)c * H * W;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (t.w[k] != 0.0f) atomicAdd(s + t.off[k], t.w[k] * g);
+    }
+}
+
 inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
@@ -294,4 +412,35 @@ extern "C" int zest_homo_warp_fwd(const float *src, const float *proj, const flo
     hipLaunchKernelGGL(homo_warp_kernel, dim3(zest_div_up(nvox, kThreads)), dim3(kThreads), 0,
                        (hipStream_t)stream, src, proj, depth, grid_in, C, D, H, W, Hp, Wp, pad, warped, grid_out);
     ZEST_RETURN_LAUNCH("zest_homo_warp_fwd");
+}
+
+extern "C" int zest_volume_cost_bwd(const float *feats_cl, const float *proj, const float *depth, int V, int C,
+                                    int D, int H, int W, int pad, const float *g_img_feat, float *g_feats_cl,
+                                    void *stream) {
+    ZEST_CHECK_ARG(feats_cl && proj && depth && g_img_feat && g_feats_cl, "zest_volume_cost_bwd: null pointer");
+    ZEST_CHECK_ARG(C == kC, "zest_volume_cost_bwd: %d feature channels (the FeatureNet top level has %d)", C, kC);
+    ZEST_CHECK_ARG(V >= 2 && V <= kMaxViews && D >= 1 && H >= 2 && W >= 2 && pad >= 0, "zest_volume_cost_bwd: bad shape");
+    const long long nvox = (long long)D * (H + 2 * pad) * (W + 2 * pad);
+    ZEST_CHECK_ARG(nvox < (1ll << 31), "zest_volume_cost_bwd: %lld voxels exceed the 32-bit index range", nvox);
+#define ZEST_SWEEP(VT)                                                                                   \
+    hipLaunchKernelGGL(volume_cost_bwd_kernel<VT>, dim3(zest_div_up(nvox, 64)), dim3(64), 0, (hipStream_t)stream, \
+                       feats_cl, proj, depth, V, D, H, W, pad, g_img_feat, g_feats_cl)
+    if (V == 3) ZEST_SWEEP(3);
+    else if (V == 4) ZEST_SWEEP(4);
+    else ZEST_SWEEP(0);
+#undef ZEST_SWEEP
+    ZEST_RETURN_LAUNCH("zest_volume_cost_bwd");
+}
+
+extern "C" int zest_homo_warp_bwd(const float *proj, const float *depth, const float *grid_in, int C, int D, int H,
+                                  int W, int Hp, int Wp, int pad, const float *g_warped, float *g_src, void *stream) {
+    ZEST_CHECK_ARG(g_warped && g_src, "zest_homo_warp_bwd: null pointer");
+    ZEST_CHECK_ARG(grid_in || (proj && depth), "zest_homo_warp_bwd: either a grid or projection + depths are needed");
+    ZEST_CHECK_ARG(C >= 1 && D >= 1 && H >= 2 && W >= 2 && Hp >= 1 && Wp >= 1 && pad >= 0, "zest_homo_warp_bwd: bad shape");
+    ZEST_CHECK_ARG(grid_in || (Hp == H + 2 * pad && Wp == W + 2 * pad), "zest_homo_warp_bwd: padded grid does not match");
+    const long long nvox = (long long)D * Hp * Wp;
+    ZEST_CHECK_ARG(nvox < (1ll << 31), "zest_homo_warp_bwd: %lld voxels exceed the 32-bit index range", nvox);
+    hipLaunchKernelGGL(homo_warp_bwd_kernel, dim3(zest_div_up(nvox, kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
+                       proj, depth, grid_in, C, D, H, W, Hp, Wp, pad, g_warped, g_src);
+    ZEST_RETURN_LAUNCH("zest_homo_warp_bwd");
 }

@@ -10,6 +10,8 @@ MLP).  Gradients exist exactly where the reference's training graph has them (SU
   CompositeFn, BlendFn   d/d(raw predictions[, blend weight]); depth samples are data.
   Prob2dFn     compute_2d_prob: the weights are detached in the reference (renderer.py:31).
 
+  VolumeCostFn, HomoWarpFn   d/d(feature maps) of the MVS plane sweep (scatter-add through the bilinear taps).
+
 The training path computes in fp32 whatever `precision` says (the bf16 engine is inference only).
 """
 import torch
@@ -141,6 +143,42 @@ def mlp_apply(net, x, time_codes=None):
         slots.append(slot)
         params += [named[name + ".weight"], named[name + ".bias"]]
     return MlpFn.apply(x, desc, tuple(slots), *params)
+
+
+class VolumeCostFn(Function):
+    """MVSNet.build_volume_cost: plane sweep forward and backward in HIP.  The gradient goes to the
+    feature maps (FeatureNet); images, homographies and depths are data (reference networks.py:1077-1140
+    under autograd gives the same: the masks are comparisons, the grid depends on cameras only)."""
+
+    @staticmethod
+    def forward(ctx, feats, imgs_lr, proj, depth, pad):
+        img_feat, masks, fcl = zest_hip.volume_cost(feats, imgs_lr, proj, depth, pad, return_feats_cl=True)
+        ctx.pad = pad
+        ctx.save_for_backward(fcl, proj, depth)
+        ctx.mark_non_differentiable(masks)
+        return img_feat, masks
+
+    @staticmethod
+    def backward(ctx, g_img_feat, g_masks):
+        fcl, proj, depth = ctx.saved_tensors
+        return zest_hip.volume_cost_bwd(fcl, proj, depth, ctx.pad, g_img_feat.contiguous()), None, None, None, None
+
+
+class HomoWarpFn(Function):
+    """utils.homo_warp with respect to the source map (the sampling positions are data)."""
+
+    @staticmethod
+    def forward(ctx, src, proj, depth, grid, pad):
+        warped, grid_out = zest_hip.homo_warp(src, proj, depth, grid, pad)
+        ctx.pad, ctx.shape = pad, tuple(src.shape)
+        ctx.save_for_backward(grid_out)
+        ctx.mark_non_differentiable(grid_out)
+        return warped, grid_out
+
+    @staticmethod
+    def backward(ctx, g_warped, g_grid):
+        (grid,) = ctx.saved_tensors
+        return zest_hip.homo_warp_bwd(g_warped.contiguous(), ctx.shape, grid=grid, pad=ctx.pad), None, None, None, None
 
 
 class DistortionFn(Function):

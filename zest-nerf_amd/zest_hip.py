@@ -63,6 +63,8 @@ _SIGS = {
     "zest_project_rays_bwd": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _i, _i, _vp, _vp, _vp]),
     "zest_volume_cost_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "zest_homo_warp_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "zest_volume_cost_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "zest_homo_warp_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "zest_volume_lookup_fwd": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     "zest_color_lookup_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "zest_encode_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp, _i, _i, _i, _vp, _i, _i, _i,
@@ -257,9 +259,10 @@ def nchw_to_nhwc(x):
     return out
 
 
-def volume_cost(feats, imgs_lr, proj, depth, pad=0):
+def volume_cost(feats, imgs_lr, proj, depth, pad=0, return_feats_cl=False):
     """Plane-sweep cost volume.  feats [V,32,H,W]; imgs_lr [V,3,H,W] (at feature resolution);
-    proj [V-1,3,4]; depth [D] -> img_feat [3V+32, D, H+2pad, W+2pad], in_masks [V, D, Hp, Wp]."""
+    proj [V-1,3,4]; depth [D] -> img_feat [3V+32, D, H+2pad, W+2pad], in_masks [V, D, Hp, Wp]
+    (and, on request, the channels-last feature maps the backward pass gathers from again)."""
     feats, imgs_lr = _dev(feats, "feats"), _dev(imgs_lr, "imgs")
     proj, depth = _dev(proj, "proj_mats"), _dev(depth, "depth_values")
     V, Cc, H, W = feats.shape
@@ -272,7 +275,35 @@ def volume_cost(feats, imgs_lr, proj, depth, pad=0):
     masks = torch.empty(V, D, Hp, Wp, device=feats.device, dtype=torch.float32)
     _check(lib().zest_volume_cost_fwd(_ptr(fcl), _ptr(icl), _ptr(proj), _ptr(depth), V, Cc, D, H, W, pad,
                                       _ptr(img_feat), _ptr(masks), _stream(feats)), "zest_volume_cost_fwd")
-    return img_feat, masks
+    return (img_feat, masks, fcl) if return_feats_cl else (img_feat, masks)
+
+
+def volume_cost_bwd(feats_cl, proj, depth, pad, g_img_feat):
+    """g_img_feat [3V+32, D, Hp, Wp] -> gradient of the feature maps [V,32,H,W] (a channels-first view of
+    the channels-last buffer the kernel scatters into)."""
+    g_img_feat, proj, depth = _dev(g_img_feat, "g_img_feat"), _dev(proj, "proj_mats"), _dev(depth, "depth_values")
+    V, H, W, Cc = feats_cl.shape
+    D = depth.shape[0]
+    if tuple(g_img_feat.shape) != (3 * V + Cc, D, H + 2 * pad, W + 2 * pad):
+        raise RuntimeError("zest_hip.volume_cost_bwd: gradient %s for V=%d D=%d H=%d W=%d pad=%d"
+                           % (tuple(g_img_feat.shape), V, D, H, W, pad))
+    g = torch.zeros_like(feats_cl)
+    _check(lib().zest_volume_cost_bwd(_ptr(feats_cl), _ptr(proj), _ptr(depth), V, Cc, D, H, W, pad, _ptr(g_img_feat),
+                                      _ptr(g), _stream(feats_cl)), "zest_volume_cost_bwd")
+    return g.permute(0, 3, 1, 2)
+
+
+def homo_warp_bwd(g_warped, src_shape, proj=None, depth=None, grid=None, pad=0):
+    """g_warped [C,D,Hp,Wp] -> g_src [C,H,W]; grid [D,Hp,Wp,2] or proj [3,4] + depth [D] as in homo_warp."""
+    g_warped = _dev(g_warped, "g_warped")
+    Cc, H, W = src_shape
+    D, Hp, Wp = g_warped.shape[1:]
+    g = torch.zeros(Cc, H, W, device=g_warped.device, dtype=torch.float32)
+    gin = _dev(grid, "src_grid") if grid is not None else None
+    proj, depth = (None, None) if gin is not None else (_dev(proj, "proj_mat"), _dev(depth, "depth_values"))
+    _check(lib().zest_homo_warp_bwd(_ptr(proj), _ptr(depth), _ptr(gin), Cc, D, H, W, Hp, Wp, pad, _ptr(g_warped),
+                                    _ptr(g), _stream(g_warped)), "zest_homo_warp_bwd")
+    return g
 
 
 def homo_warp(src, proj=None, depth=None, grid=None, pad=0):

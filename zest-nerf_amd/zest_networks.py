@@ -423,21 +423,26 @@ class MVSNet(nn.Module):
     def build_volume_cost(self, imgs, feats, proj_mats, depth_values, pad=0):
         """imgs [1,V,3,Hi,Wi]; feats [1,V,32,H,W]; proj_mats [1,V,3,4]; depth_values [1,D]
         -> (img_feat [1,3V+32,D,H+2pad,W+2pad], in_masks [1,V,D,H+2pad,W+2pad]).  One HIP launch
-        (zest_volume_cost_fwd); forward only."""
+        (zest_volume_cost_fwd); under autograd the gradient reaches `feats` through
+        zest_volume_cost_bwd (images, projections and depths are data)."""
         B, V, C, H, W = feats.shape
         if B != 1:
             raise RuntimeError("build_volume_cost: batch must be 1 (the reference assumes it too)")
-        if torch.is_grad_enabled() and (feats.requires_grad or imgs.requires_grad):
-            raise NotImplementedError("build_volume_cost: the HIP plane sweep has no backward; run the "
-                                      "volume builder under torch.no_grad() (inference / frozen MVSNet)")
         imgs_lr = torch.nn.functional.interpolate(imgs.reshape(B * V, *imgs.shape[2:]), (H, W), mode="bilinear",
                                                   align_corners=False)
         depth = depth_values.reshape(depth_values.shape[0], -1)[0]
-        img_feat, masks = zest_hip.volume_cost(feats[0], imgs_lr, proj_mats[0, 1:], depth, pad)
+        if torch.is_grad_enabled() and feats.requires_grad:
+            import zest_autograd
+            img_feat, masks = zest_autograd.VolumeCostFn.apply(feats[0].float(), imgs_lr.detach(), proj_mats[0, 1:].detach(),
+                                                               depth.detach(), pad)
+        else:
+            img_feat, masks = zest_hip.volume_cost(feats[0], imgs_lr, proj_mats[0, 1:], depth, pad)
         return img_feat[None], masks[None]
 
     def forward(self, imgs, proj_mats, near_far, pad=0, return_color=False, lindisp=False,
                 vis_test=False, test_dir=None):
+        """-> (volume_feat [1,8,128,H/4+2pad,W/4+2pad], feats, depth_values) (reference networks.py:1142-1238).
+        Differentiable with respect to the parameters of FeatureNet and CostRegNet."""
         if vis_test:
             raise NotImplementedError("MVSNet.forward: vis_test dumps are a debugging aid of the reference")
         B, V, _, H, W = imgs.shape
@@ -476,19 +481,19 @@ class _Generator(nn.Module):
         return (data - mean) / std
 
     def _volume(self, net, imgs, proj_mats, near_far, bn_batch_stats=False):
-        """Encoding volume of `net` (None -> no volume).  The HIP plane sweep is forward only, so the
-        builder runs without autograd; a builder whose parameters want gradients is refused."""
+        """Encoding volume of `net` (None -> no volume).  With autograd recording and a builder whose
+        parameters want gradients (the reference optimises generator.parameters() including the MVSNets,
+        train.py:270) the builder runs under autograd: library convolutions around the HIP plane sweep,
+        whose backward is zest_volume_cost_bwd; otherwise without a graph."""
         if net is None:
             return None
-        if torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters()):
-            raise NotImplementedError("the MVS volume builder is forward only here: freeze it "
-                                      "(requires_grad_(False)) or run under torch.no_grad()")
         if bn_batch_stats:
             net.train()         # the reference validates with batch statistics (networks.py:629, 644)
         # --precision 16 (the reference runs the whole model under AMP then): library convolutions
         # in bf16; the plane sweep and the batch norms stay fp32
         amp = int(getattr(self.args, "precision", 32) or 32) == 16 and imgs.is_cuda
-        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+        train = torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters())
+        with torch.set_grad_enabled(train), torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
             return net(imgs, proj_mats, near_far, pad=self.args.pad)[0].float()
 
 

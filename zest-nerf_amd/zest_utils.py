@@ -96,18 +96,25 @@ def homo_warp(src_feat, proj_mat, depth_values, src_grid=None, pad=0):
     src_proj @ ref_proj_inv; depth_values [1,D].  -> (warped [1,C,D,H+2pad,W+2pad],
     src_grid [1,D,W+2pad,H+2pad,2]: the reference's shape label for the normalised sampling
     positions, memory order [D][y][x]).  With src_grid given it is reused, as the reference does
-    for the colour images.  Forward only: the volume builder is run without autograd here."""
+    for the colour images.  Differentiable with respect to src_feat (HIP backward: scatter-add
+    through the bilinear taps); the sampling positions are data."""
     if src_feat.shape[0] != 1:
         raise RuntimeError("homo_warp: batch must be 1 (the reference never uses more)")
-    if torch.is_grad_enabled() and (src_feat.requires_grad or (proj_mat is not None and proj_mat.requires_grad)):
-        raise NotImplementedError("homo_warp: the HIP plane sweep has no backward; run the volume "
-                                  "builder under torch.no_grad() (inference / frozen MVSNet)")
-    if src_grid is None:
-        depth = depth_values.reshape(depth_values.shape[0], -1)[0]
+    if torch.is_grad_enabled() and proj_mat is not None and proj_mat.requires_grad:
+        raise NotImplementedError("homo_warp: no gradient with respect to the projection matrices "
+                                  "(cameras are data in the reference's training graph)")
+    depth = depth_values.reshape(depth_values.shape[0], -1)[0] if src_grid is None else None
+    gin = None
+    if src_grid is not None:
+        D, Wp, Hp = src_grid.shape[1:4]
+        gin = src_grid.reshape(D, Hp, Wp, 2)
+    if torch.is_grad_enabled() and src_feat.requires_grad:
+        import zest_autograd
+        warped, grid = zest_autograd.HomoWarpFn.apply(src_feat[0], None if gin is not None else proj_mat[0], depth, gin, pad)
+    elif gin is None:
         warped, grid = zest_hip.homo_warp(src_feat[0], proj_mat[0], depth, None, pad)
     else:
-        D, Wp, Hp = src_grid.shape[1:4]
-        warped, grid = zest_hip.homo_warp(src_feat[0], grid=src_grid.reshape(D, Hp, Wp, 2), pad=pad)
+        warped, grid = zest_hip.homo_warp(src_feat[0], grid=gin, pad=pad)
     D, Hp, Wp = grid.shape[:3]
     return warped[None], grid.view(1, D, Wp, Hp, 2)
 

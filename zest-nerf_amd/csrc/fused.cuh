@@ -257,31 +257,51 @@ __device__ __forceinline__ float block_excl_prod(float f, int c, float *total) {
 #ifndef ZEST_FUSED_WG_PER_CU
 #define ZEST_FUSED_WG_PER_CU 1
 #endif
+// Register-pressure knobs of the two-net kernels (measured: tools/kernel_resources.py):
+#ifndef ZEST_REBUILD_PTS
+#define ZEST_REBUILD_PTS 0         // 1: the point operand is rebuilt from LDS at the skip layer instead of kept in registers
+#endif
+#ifndef ZEST_GATHER_FENCE
+#define ZEST_GATHER_FENCE 1        // 1: two-net kernels with two k-tiles of static features gather one column block at a time
+#endif
+#ifndef ZEST_EARLY_DYN_GATHER
+#define ZEST_EARLY_DYN_GATHER 0    // 1: the dynamic net's gathers are issued at the start of the pass, operand parked in LDS
+#endif
 template <int EP, int NT_FEAT_S, bool DYN, int NT_FEAT_D>
 __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_CU / 4) void fused_blocks_kernel(FusedArgs a) {
     constexpr bool MOD_S = NT_FEAT_S > 0, MOD_D = NT_FEAT_D > 0;
     constexpr int NP = ep_parts(EP), CB = fused_cb(EP), BS = 16 * CB;
     constexpr int UNITS_S = stream_units(4, NT_FEAT_S, NP), UNITS_D = DYN ? stream_units(6, NT_FEAT_D, NP) : 0;
     using Ring = RingTiles<kFusedWaves, UNITS_S, UNITS_D>;
-    // LDS: weight ring | cameras of both nets | per-lane (z, dist) of the pass's samples
+    // LDS: weight ring | cameras of both nets | per-lane (z, dist) of the pass's samples | ring flags |
+    // block records | sample coordinates (the point operand is rebuilt from them at the skip layer) |
+    // with a dynamic net: the static net's per-sample results and the dynamic feature operand, parked
+    // while the other net runs (registers the engine needs: the two-net kernels spilled them before)
+    constexpr int kFdBytes = (DYN && MOD_D && ZEST_EARLY_DYN_GATHER) ? kFusedWaves * CB * (NT_FEAT_D / 2) * NP * 1024 : 0;
+    constexpr int kStBytes = DYN ? kFusedWaves * 32 * 24 : 0;
     __shared__ __attribute__((aligned(16))) char lds[kRingUnits * 1024 + 2 * kMaxViews * kCamStride * 4 +
                                                      kFusedWaves * 32 * 8 + 2 * kSlots * 4 +
-                                                     kFusedWaves * kPartialFloats * 4];
+                                                     kFusedWaves * kPartialFloats * 4 + kFusedWaves * 32 * 16 +
+                                                     kFdBytes + kStBytes];
+    static_assert(sizeof(lds) <= 163840, "LDS budget of one workgroup per CU");
     float *cams_s = reinterpret_cast<float *>(lds + kRingUnits * 1024), *cams_d = cams_s + kMaxViews * kCamStride;
     float2 *zd_lds = reinterpret_cast<float2 *>(cams_d + kMaxViews * kCamStride);
     stage_cams(a.st, cams_s);
     if (DYN) stage_cams(a.dy, cams_d);
     int *ring_flags = reinterpret_cast<int *>(zd_lds + kFusedWaves * 32);
     float *rec_lds = reinterpret_cast<float *>(ring_flags + 2 * kSlots);      // [waves][kPartialFloats]
+    float4 *x_lds = reinterpret_cast<float4 *>(rec_lds + kFusedWaves * kPartialFloats);    // [waves][32]
+    uint4 *fd_lds = reinterpret_cast<uint4 *>(x_lds + kFusedWaves * 32);                   // [waves][CB][k-tile][part][64]
+    float2 *st_lds = reinterpret_cast<float2 *>(reinterpret_cast<char *>(fd_lds) + kFdBytes);   // [waves][3][32]
 #ifdef ZEST_RING_FLAGS
     Ring::init_flags(ring_flags);
 #endif
     __syncthreads();
 
-    const int lane = threadIdx.x & 63, col = lane & 15, grp = lane >> 4, cbs = lane & (BS - 1);
+    const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const Ring tiles{lds, (gptr_u4)a.st.tiles, (gptr_u4)a.dy.tiles, lane, grp, wave,
-                     (unsigned)(wave * Ring::kPieces * 64 + lane) * 16u,
+    const Ring tiles{lds, (gptr_u4)a.st.tiles, (gptr_u4)a.dy.tiles, lane0, lane0 >> 4, wave,
+                     (unsigned)(wave * Ring::kPieces * 64 + lane0) * 16u,
                      (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds +
                          (unsigned)wave * Ring::kPieces * 1024u
 #ifdef ZEST_RING_FLAGS
@@ -309,7 +329,7 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
     // A lane's samples (column block cb: sample 16 cb + col of the block) are re-read from
     // global memory (L1/L2 hits) wherever they are needed instead of being held in registers
     // across the network: the engine needs the registers more.
-    auto fetch = [&](int g, int cb, BlockSamples &b) {
+    auto fetch = [&](int g, int cb, int col, BlockSamples &b) {
         const int r = g >= 0 ? g / a.bpr : 0, s = (g >= 0 ? g % a.bpr : 0) * BS + 16 * cb + col;
         b.valid = g >= 0 && s < a.S;
         b.x[0] = b.x[1] = b.x[2] = 0.f, b.x[3] = a.frame_idx;
@@ -361,6 +381,13 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
         unsigned long long st_last = __builtin_amdgcn_s_memtime();
         st_n++;
 #endif
+        // The lane index is made opaque once per pass: every per-lane address below (samples, LDS
+        // parking areas, record slots) is then recomputed in the pass - a handful of VALU instructions -
+        // instead of being hoisted out of the loop as ~25 loop-invariant VGPRs that the two-net kernels
+        // could only keep in scratch (11.5 MB of scratch write-back per launch in round 1).
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const int col = lane & 15, grp = lane >> 4, cbs = lane & (BS - 1);
         const int g = block_of(pass);
         int unit = 0;
         f32x4 head_s[CB], rgb_s[CB], head_d[CB], rgb_d[CB];
@@ -375,95 +402,171 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
                 for (int cb = 1; cb < CB; cb++) views[cb] = views[0];          // one ray per block
             };
         };
-        {
-            OpArr<2, NP> pts_s[CB];
-            OpArr<NT_FEAT_S / 2, NP> feat_s[CB];
+        // ---- the pass's samples: coordinates, depths and spacings go to LDS (the point operands and the
+        // compositing read them from there: no global load - and no vmcnt wait that would drain the
+        // weight DMA - once the networks run); the feature gathers of BOTH nets are issued here, while
+        // nothing else needs the registers, and the dynamic net's finished operand is parked in LDS
+        OpArr<NT_FEAT_S / 2, NP> feat_s[CB];
+#pragma unroll
+        for (int cb = 0; cb < CB; cb++) {
+            BlockSamples b;
+            fetch(g, cb, col, b);
+            if (grp == 0) {
+                zd_lds[wave * 32 + 16 * cb + col] = make_float2(b.zz, b.valid ? b.dist : -1.0f);
+                x_lds[wave * 32 + 16 * cb + col] = make_float4(b.x[0], b.x[1], b.x[2], 0.0f);
+            }
+            if constexpr (MOD_S) encode_feat_operand<EP, NT_FEAT_S / 2>(a.st, cams_s, b.x, b.pw, grp, b.valid, feat_s[cb]);
+#if ZEST_GATHER_FENCE
+            // one column block's taps at a time: both in flight together (~190 registers of tap data with
+            // 8 source views) push the two-net kernels, which hold more state, into scratch
+            if constexpr (DYN && NT_FEAT_S >= 4) __builtin_amdgcn_sched_barrier(0);
+#endif
+            if constexpr (DYN && MOD_D && ZEST_EARLY_DYN_GATHER) {
+                OpArr<NT_FEAT_D / 2, NP> fd;
+                encode_feat_operand<EP, NT_FEAT_D / 2>(a.dy, cams_d, b.x, b.pw, grp, b.valid, fd);
+#pragma unroll
+                for (int t = 0; t < NT_FEAT_D / 2; t++)
+#pragma unroll
+                    for (int pt = 0; pt < NP; pt++)
+                        fd_lds[(((wave * CB + cb) * (NT_FEAT_D / 2) + t) * NP + pt) * 64 + lane] =
+                            __builtin_bit_cast(uint4, fd.t[pt][t]);
+            }
+        }
+        // point operand of a net from the parked coordinates (C = 3: xyz; 4: xyz + frame index)
+        auto pts_static = [&](OpArr<2, NP> (&o)[CB], int token) __attribute__((always_inline)) {
 #pragma unroll
             for (int cb = 0; cb < CB; cb++) {
-                BlockSamples b;
-                fetch(g, cb, b);
-                // compositing needs z and the sample spacing after the engine: park them in LDS so
-                // that phase issues no global load (a vmcnt wait there would drain the weight DMA)
-                if (grp == 0) zd_lds[wave * 32 + 16 * cb + col] = make_float2(b.zz, b.valid ? b.dist : -1.0f);
+                int at = wave * 32 + 16 * cb + col;
+                asm volatile("" : "+v"(at) : "v"(token));          // not before `token` exists (see engine_forward)
+                const float4 xv = x_lds[at];
+                const float x4[4] = {xv.x, xv.y, xv.z, 0.0f};
 #ifdef ZEST_EXPERIMENT_NO_ENCODE        // timing experiment only
 #pragma unroll
-                for (int t = 0; t < 2; t++) pts_s[cb].t[0][t] = bf16x8{(short)lane, 1, 2, 3, 4, 5, 6, 7};
+                for (int t = 0; t < 2; t++) o[cb].t[0][t] = bf16x8{(short)lane, 1, 2, 3, 4, 5, 6, 7};
 #else
-                encode_pe_operand<EP, 3, 10, 2>(b.x, grp, pts_s[cb]);
+                encode_pe_operand<EP, 3, 10, 2>(x4, grp, o[cb]);
 #endif
-                if constexpr (MOD_S) encode_feat_operand<EP, NT_FEAT_S / 2>(a.st, cams_s, b.x, b.pw, grp, b.valid, feat_s[cb]);
             }
-            ZEST_STAMP(st_enc);
-            engine_forward<EP, CB, 4, MOD_S, NT_FEAT_S>(tiles, unit, a.st.v2 != 0, pts_s, feat_s,
-                                                        views_of(a.st, cams_s), head_s, rgb_s);
-            ZEST_STAMP(st_eng);
-        }
-        if (DYN) {
-            OpArr<3, NP> pts_d[CB];
-            OpArr<NT_FEAT_D / 2, NP> feat_d[CB];
+        };
+        auto pts_dynamic = [&](OpArr<3, NP> (&o)[CB], int token) __attribute__((always_inline)) {
 #pragma unroll
             for (int cb = 0; cb < CB; cb++) {
-                BlockSamples b;
-                fetch(g, cb, b);
-                encode_pe_operand<EP, 4, 10, 3>(b.x, grp, pts_d[cb]);
-                if constexpr (MOD_D) encode_feat_operand<EP, NT_FEAT_D / 2>(a.dy, cams_d, b.x, b.pw, grp, b.valid, feat_d[cb]);
+                int at = wave * 32 + 16 * cb + col;
+                asm volatile("" : "+v"(at) : "v"(token));
+                const float4 xv = x_lds[at];
+                const float x4[4] = {xv.x, xv.y, xv.z, a.frame_idx};
+                encode_pe_operand<EP, 4, 10, 3>(x4, grp, o[cb]);
             }
-            ZEST_STAMP(st_enc);
-            engine_forward<EP, CB, 6, MOD_D, NT_FEAT_D>(tiles, unit, false, pts_d, feat_d,
-                                                        views_of(a.dy, cams_d), head_d, rgb_d);
-            ZEST_STAMP(st_eng);
+        };
+        ZEST_STAMP(st_enc);
+        if constexpr (ZEST_REBUILD_PTS) {
+            engine_forward<EP, CB, 4, MOD_S, NT_FEAT_S>(tiles, unit, a.st.v2 != 0, pts_static, feat_s,
+                                                        views_of(a.st, cams_s), head_s, rgb_s);
+        } else {
+            OpArr<2, NP> pts_keep[CB];
+            pts_static(pts_keep, 0);
+            auto pts_copy = [&](OpArr<2, NP> (&o)[CB], int) __attribute__((always_inline)) {
+#pragma unroll
+                for (int cb = 0; cb < CB; cb++) o[cb] = pts_keep[cb];
+            };
+            engine_forward<EP, CB, 4, MOD_S, NT_FEAT_S>(tiles, unit, a.st.v2 != 0, pts_copy, feat_s,
+                                                        views_of(a.st, cams_s), head_s, rgb_s);
         }
+        ZEST_STAMP(st_eng);
         // ---- per-block compositing on lanes 0 .. BS-1 (sample = lane): rgb rows 0-2, head rows 0, 1
         // sit in elements 0-2 / 0, 1 of lane group 0 of each column block
+        float rec[kPartialFloats];
+#pragma unroll
+        for (int i = 0; i < kPartialFloats; i++) rec[i] = 0.f;
+        float zz, dist, cr, cg, cb, al_s;
+        bool valid;
         {
-            BlockSamples b;
-            {
-                const float2 zd = zd_lds[wave * 32 + cbs];
-                b.zz = zd.x, b.dist = fmaxf(zd.y, 0.0f), b.valid = zd.y >= 0.0f;
-            }
-            float cr = join(rgb_s, 0), cg = join(rgb_s, 1), cb = join(rgb_s, 2), sg = join(head_s, 0);
+            const float2 zd = zd_lds[wave * 32 + cbs];
+            zz = zd.x, dist = fmaxf(zd.y, 0.0f), valid = zd.y >= 0.0f;
+            float sg = join(head_s, 0);
+            cr = join(rgb_s, 0), cg = join(rgb_s, 1), cb = join(rgb_s, 2);
             if (a.st.v2) {   // 'v2' nets activate inside the network; the compositor does it again
                 cr = zest_sigmoid(cr), cg = zest_sigmoid(cg), cb = zest_sigmoid(cb), sg = fmaxf(sg, 0.f);
             }
             cr = zest_sigmoid(cr), cg = zest_sigmoid(cg), cb = zest_sigmoid(cb);
-            const float al_s = b.valid ? 1.0f - expf(-fmaxf(sg, 0.f) * b.dist) : 0.0f;
-            float rec[kPartialFloats];
+            al_s = valid ? 1.0f - expf(-fmaxf(sg, 0.f) * dist) : 0.0f;
+            float tot;
+            const float w = al_s * block_excl_prod<BS>(1.0f - al_s + 1e-10f, cbs, &tot);
+            rec[0] = tot;
+            rec[1] = block_sum<BS>(w * cr), rec[2] = block_sum<BS>(w * cg), rec[3] = block_sum<BS>(w * cb);
+            rec[4] = block_sum<BS>(w * zz), rec[5] = block_sum<BS>(w);
+        }
+        if (DYN) {
+            // the static net's per-sample results wait in LDS while the dynamic net has the registers
+            const float blend_s = zest_sigmoid(join(head_s, 1));
+            if (lane < BS) {
+                st_lds[(wave * 3 + 0) * 32 + lane] = make_float2(cr, cg);
+                st_lds[(wave * 3 + 1) * 32 + lane] = make_float2(cb, al_s);
+                st_lds[(wave * 3 + 2) * 32 + lane] = make_float2(blend_s, 0.0f);
+            }
+            OpArr<NT_FEAT_D / 2, NP> feat_d[CB];
+            if constexpr (MOD_D && ZEST_EARLY_DYN_GATHER) {
 #pragma unroll
-            for (int i = 0; i < kPartialFloats; i++) rec[i] = 0.f;
-            {
-                float tot;
-                const float w = al_s * block_excl_prod<BS>(1.0f - al_s + 1e-10f, cbs, &tot);
-                rec[0] = tot;
-                rec[1] = block_sum<BS>(w * cr), rec[2] = block_sum<BS>(w * cg), rec[3] = block_sum<BS>(w * cb);
-                rec[4] = block_sum<BS>(w * b.zz), rec[5] = block_sum<BS>(w);
-            }
-            if (DYN) {
-                const float blend = zest_sigmoid(join(head_s, 1));
-                const float er = zest_sigmoid(join(rgb_d, 0)), eg = zest_sigmoid(join(rgb_d, 1)),
-                            eb = zest_sigmoid(join(rgb_d, 2));
-                const float sg_d = join(head_d, 0);
-                const float a_fg = b.valid ? 1.0f - expf(-fmaxf(sg_d, 0.f) * b.dist) : 0.0f;
-                const float a_d = a_fg * blend, a_st = al_s * (1.0f - blend);
-                float tot_b, tot_f;
-                const float Tb = block_excl_prod<BS>((1.0f - a_d) * (1.0f - a_st) + 1e-10f, cbs, &tot_b);
-                const float wf = a_fg * block_excl_prod<BS>(1.0f - a_fg + 1e-10f, cbs, &tot_f);
-                const float wd = Tb * a_d, ws = Tb * a_st;
-                rec[6] = tot_b;
-                rec[7] = block_sum<BS>(wd * er + ws * cr), rec[8] = block_sum<BS>(wd * eg + ws * cg);
-                rec[9] = block_sum<BS>(wd * eb + ws * cb), rec[10] = block_sum<BS>((wd + ws) * b.zz);
-                rec[11] = block_sum<BS>(wd);
-                rec[12] = tot_f;
-                rec[13] = block_sum<BS>(wf * er), rec[14] = block_sum<BS>(wf * eg), rec[15] = block_sum<BS>(wf * eb);
-                rec[16] = block_sum<BS>(wf * b.zz);
-            }
-            if (lane == 0 && g >= 0) {
-                // records go to HBM for combine_kernel, or stay in LDS when the pass holds whole rays
-                float4 *o = a.rays_per_pass > 0 ? reinterpret_cast<float4 *>(rec_lds + wave * kPartialFloats)
-                                                : reinterpret_cast<float4 *>(a.partials + (size_t)g * kPartialFloats);
+                for (int cbi = 0; cbi < CB; cbi++)
 #pragma unroll
-                for (int i = 0; i < (DYN ? 5 : 2); i++)
-                    o[i] = make_float4(rec[4 * i], rec[4 * i + 1], rec[4 * i + 2], rec[4 * i + 3]);
+                    for (int t = 0; t < NT_FEAT_D / 2; t++)
+#pragma unroll
+                        for (int pt = 0; pt < NP; pt++)
+                            feat_d[cbi].t[pt][t] = __builtin_bit_cast(
+                                bf16x8, fd_lds[(((wave * CB + cbi) * (NT_FEAT_D / 2) + t) * NP + pt) * 64 + lane]);
+            } else if constexpr (MOD_D) {
+                // the dynamic net's gathers, now that the static net's registers are free (issued together
+                // with the static ones they push the gather phase into scratch)
+#pragma unroll
+                for (int cbi = 0; cbi < CB; cbi++) {
+                    BlockSamples b;
+                    fetch(g, cbi, col, b);
+                    encode_feat_operand<EP, NT_FEAT_D / 2>(a.dy, cams_d, b.x, b.pw, grp, b.valid, feat_d[cbi]);
+                }
             }
+            ZEST_STAMP(st_comp);
+            if constexpr (ZEST_REBUILD_PTS) {
+                engine_forward<EP, CB, 6, MOD_D, NT_FEAT_D>(tiles, unit, false, pts_dynamic, feat_d,
+                                                            views_of(a.dy, cams_d), head_d, rgb_d);
+            } else {
+                OpArr<3, NP> pts_keep[CB];
+                pts_dynamic(pts_keep, 0);
+                auto pts_copy = [&](OpArr<3, NP> (&o)[CB], int) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int cb = 0; cb < CB; cb++) o[cb] = pts_keep[cb];
+                };
+                engine_forward<EP, CB, 6, MOD_D, NT_FEAT_D>(tiles, unit, false, pts_copy, feat_d,
+                                                            views_of(a.dy, cams_d), head_d, rgb_d);
+            }
+            ZEST_STAMP(st_eng);
+            const float2 s0 = st_lds[(wave * 3 + 0) * 32 + cbs], s1 = st_lds[(wave * 3 + 1) * 32 + cbs],
+                         s2 = st_lds[(wave * 3 + 2) * 32 + cbs];
+            cr = s0.x, cg = s0.y, cb = s1.x, al_s = s1.y;
+            const float blend = s2.x;
+            const float er = zest_sigmoid(join(rgb_d, 0)), eg = zest_sigmoid(join(rgb_d, 1)),
+                        eb = zest_sigmoid(join(rgb_d, 2));
+            const float sg_d = join(head_d, 0);
+            const float a_fg = valid ? 1.0f - expf(-fmaxf(sg_d, 0.f) * dist) : 0.0f;
+            const float a_d = a_fg * blend, a_st = al_s * (1.0f - blend);
+            float tot_b, tot_f;
+            const float Tb = block_excl_prod<BS>((1.0f - a_d) * (1.0f - a_st) + 1e-10f, cbs, &tot_b);
+            const float wf = a_fg * block_excl_prod<BS>(1.0f - a_fg + 1e-10f, cbs, &tot_f);
+            const float wd = Tb * a_d, ws = Tb * a_st;
+            rec[6] = tot_b;
+            rec[7] = block_sum<BS>(wd * er + ws * cr), rec[8] = block_sum<BS>(wd * eg + ws * cg);
+            rec[9] = block_sum<BS>(wd * eb + ws * cb), rec[10] = block_sum<BS>((wd + ws) * zz);
+            rec[11] = block_sum<BS>(wd);
+            rec[12] = tot_f;
+            rec[13] = block_sum<BS>(wf * er), rec[14] = block_sum<BS>(wf * eg), rec[15] = block_sum<BS>(wf * eb);
+            rec[16] = block_sum<BS>(wf * zz);
+        }
+        if (lane == 0 && g >= 0) {
+            // records go to HBM for combine_kernel, or stay in LDS when the pass holds whole rays
+            float4 *o = a.rays_per_pass > 0 ? reinterpret_cast<float4 *>(rec_lds + wave * kPartialFloats)
+                                            : reinterpret_cast<float4 *>(a.partials + (size_t)g * kPartialFloats);
+#pragma unroll
+            for (int i = 0; i < (DYN ? 5 : 2); i++)
+                o[i] = make_float4(rec[4 * i], rec[4 * i + 1], rec[4 * i + 2], rec[4 * i + 3]);
         }
         if (a.rays_per_pass > 0) {
             // The blocks of a ray sit in consecutive waves of this pass: after one rendezvous the
@@ -480,12 +583,12 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
     }
     tiles.drain();
 #ifdef ZEST_RING_FLAGS
-    if (tiles.poisoned && lane == 0) {
+    if (tiles.poisoned && lane0 == 0) {
         a.partials[0] = __builtin_nanf("");   // make a protocol failure visible
     }
 #endif
 #ifdef ZEST_STAMPS
-    if (a.stamps && lane == 0) {
+    if (a.stamps && lane0 == 0) {
         unsigned long long *o = a.stamps + (size_t)(blockIdx.x * kFusedWaves + wave) * 8;
         o[0] = __builtin_amdgcn_s_memtime() - st_t0, o[1] = st_enc, o[2] = st_eng, o[3] = st_comp;
         o[4] = tiles.t_wait, o[5] = tiles.t_issue, o[6] = __builtin_amdgcn_s_memrealtime() - st_r0,

@@ -515,13 +515,14 @@ __device__ __forceinline__ void engine_layer(const Tiles &tiles, int &unit, bool
 
 // The whole network for CB column blocks of 16 samples, reading the stream from unit `unit` on
 // (advanced to the end of the net's padded stream).  pts/feat: encoder operands in plan position
-// order, NU_* = their logical stream tiles per row block = 2 x k-tiles; `views_fn(views)` builds
-// the direction operand when it is first needed (op 10) so that it does not occupy registers
-// through the trunk.  Results per column block: head (lane group g: rows 4g .. 4g+3 of the head
+// order, NU_* = their logical stream tiles per row block = 2 x k-tiles.  `pts_fn(pts)` builds the
+// point operand; it is called twice, `pts_fn(pts, token)`, for layer 0 and for the skip layer 5, so
+// the operand does not occupy registers through layers 1-4 (a caller that prefers to keep it hands
+// out copies);
+// `views_fn(views)` builds the direction operand when it is first needed (op 10).  Results per column block: head (lane group g: rows 4g .. 4g+3 of the head
 // tile; row 0 alpha, rows 1.. extra heads) and rgb (group 0: rows 0-2), raw.
-template <int EP, int CB, int NU_PTS, bool MOD, int NU_FEAT, class Tiles, class ViewsFn>
-__device__ __forceinline__ void engine_forward(const Tiles &tiles, int &unit, bool v2,
-                                               const OpArr<NU_PTS / 2, ep_parts(EP)> (&pts)[CB],
+template <int EP, int CB, int NU_PTS, bool MOD, int NU_FEAT, class Tiles, class PtsFn, class ViewsFn>
+__device__ __forceinline__ void engine_forward(const Tiles &tiles, int &unit, bool v2, PtsFn pts_fn,
                                                const OpArr<NU_FEAT / 2, ep_parts(EP)> (&feat)[CB], ViewsFn views_fn,
                                                f32x4 (&head)[CB], f32x4 (&rgb)[CB]) {
     constexpr int KP = NU_PTS / 2, KF = NU_FEAT / 2, NP = ep_parts(EP);
@@ -530,12 +531,22 @@ __device__ __forceinline__ void engine_forward(const Tiles &tiles, int &unit, bo
     OpArr<0, NP> none[CB];
     f32x4 unused[CB];
     const int unit0 = unit;
-    engine_layer<EP, CB, 8, KP, 0, MOD, KF, true, 0>(tiles, unit, v2, pts, none, feat, hA, unused);
+    {
+        OpArr<KP, NP> pts[CB];
+        pts_fn(pts, 0);
+        engine_layer<EP, CB, 8, KP, 0, MOD, KF, true, 0>(tiles, unit, v2, pts, none, feat, hA, unused);
+    }
     engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hA, none, feat, hB, unused);
     engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hB, none, feat, hA, unused);
     engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hA, none, feat, hB, unused);
     engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hB, none, feat, hA, unused);
-    engine_layer<EP, CB, 8, KP, 8, MOD, KF, true, 0>(tiles, unit, v2, pts, hA, feat, hB, unused);
+    {
+        // `token` is a value layer 4 has just produced: a builder that ties its address arithmetic to it
+        // cannot be scheduled ahead of layers 1-4 (where its registers would be live all along)
+        OpArr<KP, NP> pts[CB];
+        pts_fn(pts, (int)hA[CB - 1].t[0][7][0]);
+        engine_layer<EP, CB, 8, KP, 8, MOD, KF, true, 0>(tiles, unit, v2, pts, hA, feat, hB, unused);
+    }
     engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hB, none, feat, hA, unused);
     engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hA, none, feat, hB, unused);
     // trunk output in hB

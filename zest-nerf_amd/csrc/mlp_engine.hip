@@ -113,7 +113,13 @@ __global__ __launch_bounds__(kMlpWaves * 64, kMlpWaves / 4) void mlp_engine_kern
         };
         f32x4 headt[CB], rgbt[CB];
         int unit = 0;
-        engine_forward<EP, CB, NT_PTS, MOD, NT_FEAT>(tiles, unit, v2 != 0, pts, feat, views_fn, headt, rgbt);
+        // the rows of x come from global memory: the point operand is built once and kept (a reload in
+        // the middle of the engine would drain the weight DMA behind its vmcnt wait)
+        auto pts_fn = [&](OpArr<NT_PTS / 2, NP> (&o)[CB], int) {
+#pragma unroll
+            for (int cb = 0; cb < CB; cb++) o[cb] = pts[cb];
+        };
+        engine_forward<EP, CB, NT_PTS, MOD, NT_FEAT>(tiles, unit, v2 != 0, pts_fn, feat, views_fn, headt, rgbt);
 #pragma unroll
         for (int cb = 0; cb < CB; cb++) {
             const long long m = m_base + 16 * cb + col;

@@ -117,13 +117,13 @@ def flops_per_ray_batch(d):
     return f * d.R * d.S, f
 
 
-def pmc_traffic(workload):
+def pmc_traffic(workload, mode="bf16"):
     """HBM bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes,
     gfx950 correction: FETCH_SIZE counts half of a wide coalesced read) and archived by
     tools/pmc_traffic.py; None when no measurement exists for the workload."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
+            return json.load(f).get(workload if mode == "bf16" else "%s@%s" % (workload, mode), {}).get("hbm_bytes_per_launch")
     except (OSError, ValueError):
         return None
 
@@ -396,7 +396,7 @@ def main():
                        "ranks": dist.get_world_size() if dist is not None else 1,
                        "backend": ("rccl" if dist is not None else "none")},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                         "frac": ach / peak, "traffic": pmc_traffic(a.workload),
+                         "frac": ach / peak, "traffic": pmc_traffic(a.workload, a.mode),
                          "kernel": "fused_blocks_kernel (rays finished in-kernel when a pass holds whole rays; else + fused_combine_kernel)",
                          "kernel_ms": k_ms, "flop_per_sample": fps,
                          "note": "achieved = algorithmic MLP FLOPs of one launch / HIP-event time of the "
@@ -417,7 +417,8 @@ def main():
             ach_m = fl / (km * 1e-3) / 1e12
             modes[m] = {"value": d.R * a.steps / el_m, "unit": "rays/s", "ms_per_step": el_m / a.steps * 1e3,
                         "kernel_ms": km, "roofline": {"bound": "mfma", "achieved": ach_m, "peak": MODES[m][2],
-                                                      "unit": "TFLOP/s", "frac": ach_m / MODES[m][2]}}
+                                                      "unit": "TFLOP/s", "frac": ach_m / MODES[m][2],
+                                                      "traffic": pmc_traffic(a.workload, m)}}
         modes["f16x3"]["note"] = ("fp32 mode of the fused renderer: every product is 3 fp16 MFMAs (hi*hi + hi*lo + lo*hi); "
                                   "achieved counts the ALGORITHMIC FLOPs once, so frac <= 1/3 by construction; "
                                   "executed MFMA work = 3x; against the fp32 MFMA peak (157.3 TFLOP/s) the same "

@@ -26,6 +26,8 @@ struct DevPlan {
 std::mutex g_mu;
 std::map<std::tuple<int, int, int, int, int, int, int, int>, DevPlan *> g_plans;
 
+constexpr int kOrderBwd = 99;       // key of the training path's backward-data stream (bf16, build_bwd_plan)
+
 // Plans are built once per (shape, precision, order) and kept for the life of the process.
 DevPlan *get_plan(const zest_mlp_desc &d, int precision, int order, bool need_tables) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -36,7 +38,9 @@ DevPlan *get_plan(const zest_mlp_desc &d, int precision, int order, bool need_ta
     if (!dp) {
         dp = new DevPlan();
         const char *err = nullptr;
-        if (!zest::build_plan(d, precision, order, &dp->plan, &err)) {
+        const bool ok = order == kOrderBwd ? zest::build_bwd_plan(d, &dp->plan, &err)
+                                           : zest::build_plan(d, precision, order, &dp->plan, &err);
+        if (!ok) {
             zest_set_error("MLP shape not supported: %s", err);
             delete dp;
             return nullptr;
@@ -236,6 +240,31 @@ F32Prog make_f32_prog(const MlpPlan &p) {
 }
 
 }  // namespace
+
+// the training path's transposed stream: same packer, other plan (mlp_train16.hip calls these)
+namespace zest {
+size_t bwd_stream_bytes(const zest_mlp_desc &d) {
+    DevPlan *dp = get_plan(d, ZEST_PREC_BF16, kOrderBwd, false);
+    return dp ? dp->plan.bytes : 0;
+}
+int bwd_stream_units_of(const zest_mlp_desc &d) {
+    DevPlan *dp = get_plan(d, ZEST_PREC_BF16, kOrderBwd, false);
+    return dp ? dp->plan.n_tiles : -1;
+}
+int pack_bwd_stream(const zest_mlp_desc &d, const float *const *params, void *packed, hipStream_t stream) {
+    DevPlan *dp = get_plan(d, ZEST_PREC_BF16, kOrderBwd, true);
+    if (!dp) return (int)hipErrorInvalidValue;
+    const MlpPlan &p = dp->plan;
+    ParamTable pt;
+    for (int i = 0; i < 2 * ZEST_P_COUNT; i++) pt.p[i] = params[i];
+    const size_t n_w = p.tile_src.size(), n_h = p.hdr_src.size();
+    hipLaunchKernelGGL(pack_kernel<ZEST_PREC_BF16>, dim3(zest_div_up(n_w, 256)), dim3(256), 0, stream, pt, dp->tile_src,
+                       n_w, dp->bias_src, (size_t)0, dp->unit_part, (float *)packed, packed);
+    hipLaunchKernelGGL(pack_headers_kernel, dim3(zest_div_up(n_h, 256)), dim3(256), 0, stream, pt, dp->hdr_src, n_h,
+                       (char *)packed);
+    ZEST_RETURN_LAUNCH("zest_mlp_train16_pack");
+}
+}  // namespace zest
 
 extern "C" size_t zest_mlp_packed_bytes(const zest_mlp_desc *desc, int precision) {
     if (!desc) return 0;

@@ -408,12 +408,20 @@ struct RowBlockPre {
 // reads are software-pipelined by hand, in source order: every tile is requested kPrefetch tiles
 // before the MFMAs that use it, and the NEXT row block's header and first tiles are requested
 // before the CURRENT epilogue, whose VALU instructions cover their latency.
-template <int EP, int CB, int NJB, int NKA, int NKB, bool MOD, int NKF, bool RELU, int MODE, class Tiles>
+// A sink sees every finished operand tile of the layers that have one (training: the activation stash):
+//   sink(id, jb, cb, v)   id: 0-7 trunk layers, 8 feature_linear, 9 view layer; v: the 8 fp32 values
+struct NoSink {
+    __device__ __forceinline__ void operator()(int, int, int, const float (&)[8]) const {}
+};
+
+template <int EP, int CB, int NJB, int NKA, int NKB, bool MOD, int NKF, bool RELU, int MODE, class Tiles,
+          class Sink = NoSink>
 __device__ __forceinline__ void engine_layer(const Tiles &tiles, int &unit, bool v2,
                                              const OpArr<NKA, ep_parts(EP)> (&opa)[CB],
                                              const OpArr<NKB, ep_parts(EP)> (&opb)[CB],
                                              const OpArr<NKF, ep_parts(EP)> (&opf)[CB],
-                                             OpArr<8, ep_parts(EP)> (&out)[CB], f32x4 (&keep)[CB]) {
+                                             OpArr<8, ep_parts(EP)> (&out)[CB], f32x4 (&keep)[CB],
+                                             int sink_id = 0, const Sink &sink = Sink()) {
     constexpr int NP = ep_parts(EP);
     constexpr bool X3 = EP == ZEST_PREC_F16X3;
     constexpr int NM = MOD ? 2 * NKF : 0, T = NM + 2 * (NKA + NKB);     // tiles per row block
@@ -506,6 +514,7 @@ __device__ __forceinline__ void engine_layer(const Tiles &tiles, int &unit, bool
             }
             if (MODE == 0) {
                 store_tile<EP>(v, out[cb], jb);
+                sink(sink_id, jb, cb, v);
             } else if (jb == 0) {
                 keep[cb] = f32x4{v[0], v[1], v[2], v[3]};
             }
@@ -521,10 +530,10 @@ __device__ __forceinline__ void engine_layer(const Tiles &tiles, int &unit, bool
 // out copies);
 // `views_fn(views)` builds the direction operand when it is first needed (op 10).  Results per column block: head (lane group g: rows 4g .. 4g+3 of the head
 // tile; row 0 alpha, rows 1.. extra heads) and rgb (group 0: rows 0-2), raw.
-template <int EP, int CB, int NU_PTS, bool MOD, int NU_FEAT, class Tiles, class PtsFn, class ViewsFn>
+template <int EP, int CB, int NU_PTS, bool MOD, int NU_FEAT, class Tiles, class PtsFn, class ViewsFn, class Sink = NoSink>
 __device__ __forceinline__ void engine_forward(const Tiles &tiles, int &unit, bool v2, PtsFn pts_fn,
                                                const OpArr<NU_FEAT / 2, ep_parts(EP)> (&feat)[CB], ViewsFn views_fn,
-                                               f32x4 (&head)[CB], f32x4 (&rgb)[CB]) {
+                                               f32x4 (&head)[CB], f32x4 (&rgb)[CB], const Sink &sink = Sink()) {
     constexpr int KP = NU_PTS / 2, KF = NU_FEAT / 2, NP = ep_parts(EP);
     static_assert(NU_PTS % 2 == 0 && NU_FEAT % 2 == 0, "units per row block come in row-tile pairs");
     OpArr<8, NP> hA[CB], hB[CB];
@@ -534,27 +543,27 @@ __device__ __forceinline__ void engine_forward(const Tiles &tiles, int &unit, bo
     {
         OpArr<KP, NP> pts[CB];
         pts_fn(pts, 0);
-        engine_layer<EP, CB, 8, KP, 0, MOD, KF, true, 0>(tiles, unit, v2, pts, none, feat, hA, unused);
+        engine_layer<EP, CB, 8, KP, 0, MOD, KF, true, 0>(tiles, unit, v2, pts, none, feat, hA, unused, 0, sink);
     }
-    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hA, none, feat, hB, unused);
-    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hB, none, feat, hA, unused);
-    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hA, none, feat, hB, unused);
-    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hB, none, feat, hA, unused);
+    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hA, none, feat, hB, unused, 1, sink);
+    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hB, none, feat, hA, unused, 2, sink);
+    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hA, none, feat, hB, unused, 3, sink);
+    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hB, none, feat, hA, unused, 4, sink);
     {
         // `token` is a value layer 4 has just produced: a builder that ties its address arithmetic to it
         // cannot be scheduled ahead of layers 1-4 (where its registers would be live all along)
         OpArr<KP, NP> pts[CB];
         pts_fn(pts, (int)hA[CB - 1].t[0][7][0]);
-        engine_layer<EP, CB, 8, KP, 8, MOD, KF, true, 0>(tiles, unit, v2, pts, hA, feat, hB, unused);
+        engine_layer<EP, CB, 8, KP, 8, MOD, KF, true, 0>(tiles, unit, v2, pts, hA, feat, hB, unused, 5, sink);
     }
-    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hB, none, feat, hA, unused);
-    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hA, none, feat, hB, unused);
+    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hB, none, feat, hA, unused, 6, sink);
+    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hA, none, feat, hB, unused, 7, sink);
     // trunk output in hB
     engine_layer<EP, CB, 1, 8, 0, false, KF, false, 1>(tiles, unit, v2, hB, none, feat, hA, head);
-    engine_layer<EP, CB, 8, 8, 0, false, KF, false, 0>(tiles, unit, v2, hB, none, feat, hA, unused);
+    engine_layer<EP, CB, 8, 8, 0, false, KF, false, 0>(tiles, unit, v2, hB, none, feat, hA, unused, 8, sink);
     OpArr<1, NP> views[CB];
     views_fn(views);
-    engine_layer<EP, CB, 4, 8, 1, false, KF, true, 0>(tiles, unit, v2, hA, views, feat, hB, unused);
+    engine_layer<EP, CB, 4, 8, 1, false, KF, true, 0>(tiles, unit, v2, hA, views, feat, hB, unused, 9, sink);
     // rgb: 128 hidden features = first 4 k-tiles of hB
     OpArr<4, NP> h128[CB];
 #pragma unroll

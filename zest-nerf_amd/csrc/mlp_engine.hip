@@ -6,68 +6,49 @@
 // rows through the network in registers; only the operand source (rows of x instead of the
 // in-kernel encoders) and the sink (raw network outputs instead of compositing) differ.
 #include "mlp_engine.cuh"
+#include "mlp_train16.h"
+#include "mlp_operands.cuh"
 
 namespace zest {
-
-// Operand assembly.  The position -> input-column maps of the plan (mlp_plan.hip pe_map_acc,
-// feat_map_acc) are affine in the lane group, so a lane needs one row pointer per operand and
-// compile-time offsets - no table lookups, no per-element address arithmetic:
-//   PE operand of C coordinates, L bands: element e of k-tile kt is m = 8 kt + e;
-//     m < (L/2) C:  column C + 2C (2 (m / C) + (g >> 1)) + (g & 1) C + m % C
-//                   = [C + 4C (m / C) + m % C] + [(g >> 1) 2C + (g & 1) C];   m = (L/2) C: column g (< C)
-//   feature operand: quad q = 8 kt + 2 g + (e >> 2), channel c = e & 3:
-//     q = 0, 2: volume columns c, 4 + c;  q = 1, 3: columns 8 + c, 12 + c;  q >= 4: column 4 q + c
-template <int EP, int C, int L, int NK>
-__device__ __forceinline__ void load_pe_operand(const float *__restrict__ xrow, bool valid, int grp,
-                                                OpArr<NK, ep_parts(EP)> &op) {
-    const float *xg = xrow + (grp >> 1) * 2 * C + (grp & 1) * C;
-    const float raw = (valid && grp < C) ? xrow[grp < C ? grp : 0] : 0.0f;
-#pragma unroll
-    for (int t = 0; t < NK; t++) {
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const int m = 8 * t + e;
-            if (m < (L / 2) * C)
-                v[e] = valid ? xg[C + 4 * C * (m / C) + m % C] : 0.0f;
-            else
-                v[e] = m == (L / 2) * C ? raw : 0.0f;
-        }
-        store_tile<EP>(v, op, t);
-    }
-}
-
-template <int EP, int NK>
-__device__ __forceinline__ void load_feat_operand(const float *__restrict__ xf, int F, bool valid, int grp,
-                                                  OpArr<NK, ep_parts(EP)> &op) {
-#pragma unroll
-    for (int t = 0; t < NK; t++) {
-        // first columns of this lane's two quads
-        int ca, cb;
-        if (t == 0) {
-            ca = grp == 0 ? 0 : (grp == 1 ? 4 : 8 * grp);              // quads 0, 2, 4, 6
-            cb = grp == 0 ? 8 : (grp == 1 ? 12 : 8 * grp + 4);         // quads 1, 3, 5, 7
-        } else {
-            ca = 32 * t + 8 * grp, cb = ca + 4;
-        }
-        const bool va = valid && ca + 4 <= F, vb = valid && cb + 4 <= F;
-        const float *pa = xf + (va ? ca : 0), *pb = xf + (vb ? cb : 0);
-        float v[8];
-#pragma unroll
-        for (int c = 0; c < 4; c++) v[c] = va ? pa[c] : 0.0f, v[4 + c] = vb ? pb[c] : 0.0f;
-        store_tile<EP>(v, op, t);
-    }
-}
 
 // A wave runs CB column blocks of 16 rows (lane: column l & 15, group l >> 4): two, or one where
 // every operand is a register pair (split fp16).
 constexpr int kMlpWaves = 8;
 constexpr int mlp_cb(int EP) { return EP == ZEST_PREC_F16X3 ? 1 : 2; }
 
-template <int EP, int NT_PTS, bool MOD, int NT_FEAT>
+// Training forward: every layer's output operand tiles go to the activation stash as they are
+// produced (1 KiB per tile and column block, written by the wave that holds it: fully coalesced), plus
+// one bit per element "was active" for the layers with a ReLU.  Layout (mlp_train16.h):
+//   tiles  [block][kStashTiles][CB][64 lanes] x 16 B      tile = 8 * layer + k-tile (layers 0-7),
+//                                                          64 + k-tile feature_linear, 72 + k-tile view layer
+//   masks  [block][kStashMasks][CB][64 lanes] x 8 B       bit 8 * k-tile + element; 0-7 trunk, 8 view layer
+template <int CB>
+struct StashSink {
+    uint4 *tiles;
+    uint2 *masks;
+    long long block;
+    int lane;
+    mutable unsigned lo[CB], hi[CB];
+    __device__ __forceinline__ void operator()(int id, int jb, int cb, const float (&v)[8]) const {
+        const int t = id < 8 ? 8 * id + jb : (id == 8 ? 64 + jb : 72 + jb);
+        uint4 q = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+        tiles[((block * kStashTiles + t) * CB + cb) * 64 + lane] = q;
+        if (id == 8) return;                                     // feature_linear has no activation
+        unsigned bits = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) bits |= (v[i] > 0.0f ? 1u : 0u) << i;
+        if (jb == 0) lo[cb] = 0, hi[cb] = 0;
+        if (jb < 4) lo[cb] |= bits << (8 * jb);
+        else hi[cb] |= bits << (8 * (jb - 4));
+        const int last = id == 9 ? 3 : 7, mid = id == 9 ? 8 : id;
+        if (jb == last) masks[((block * kStashMasks + mid) * CB + cb) * 64 + lane] = make_uint2(lo[cb], hi[cb]);
+    }
+};
+
+template <int EP, int NT_PTS, bool MOD, int NT_FEAT, bool TRAIN = false>
 __global__ __launch_bounds__(kMlpWaves * 64, kMlpWaves / 4) void mlp_engine_kernel(
     const uint4 *__restrict__ tiles_g, const float *__restrict__ x, int M, int P, int F, int C_in, int C_out, int head, int v2,
-    int act_out, float *__restrict__ out) {
+    int act_out, float *__restrict__ out, uint4 *__restrict__ stash_tiles = nullptr, uint2 *__restrict__ stash_masks = nullptr) {
     constexpr int NP = ep_parts(EP), CB = mlp_cb(EP), UNITS = stream_units(NT_PTS, MOD ? NT_FEAT : 0, NP);
     using Ring = RingTiles<kMlpWaves, UNITS, 0>;
     __shared__ __attribute__((aligned(16))) char lds[kRingUnits * 1024 + 2 * kSlots * 4];
@@ -119,7 +100,12 @@ __global__ __launch_bounds__(kMlpWaves * 64, kMlpWaves / 4) void mlp_engine_kern
 #pragma unroll
             for (int cb = 0; cb < CB; cb++) o[cb] = pts[cb];
         };
-        engine_forward<EP, CB, NT_PTS, MOD, NT_FEAT>(tiles, unit, v2 != 0, pts_fn, feat, views_fn, headt, rgbt);
+        if constexpr (TRAIN) {
+            const StashSink<CB> sink{stash_tiles, stash_masks, (long long)pass * kMlpWaves + wave, lane, {}, {}};
+            engine_forward<EP, CB, NT_PTS, MOD, NT_FEAT>(tiles, unit, v2 != 0, pts_fn, feat, views_fn, headt, rgbt, sink);
+        } else {
+            engine_forward<EP, CB, NT_PTS, MOD, NT_FEAT>(tiles, unit, v2 != 0, pts_fn, feat, views_fn, headt, rgbt);
+        }
 #pragma unroll
         for (int cb = 0; cb < CB; cb++) {
             const long long m = m_base + 16 * cb + col;
@@ -146,9 +132,9 @@ __global__ __launch_bounds__(kMlpWaves * 64, kMlpWaves / 4) void mlp_engine_kern
     tiles.drain();
 }
 
-template <int EP, int NT_PTS, bool MOD, int NT_FEAT>
+template <int EP, int NT_PTS, bool MOD, int NT_FEAT, bool TRAIN = false>
 static int launch_one(const MlpPlan &p, const void *tiles, const float *x, int M,
-                      float *out, hipStream_t stream) {
+                      float *out, hipStream_t stream, void *stash_tiles = nullptr, void *stash_masks = nullptr) {
     constexpr int units = stream_units(NT_PTS, MOD ? NT_FEAT : 0, ep_parts(EP));
     if (p.n_tiles != units) {
         zest_set_error("zest_mlp_fwd(engine): plan has %d stream units, kernel expects %d", p.n_tiles, units);
@@ -164,10 +150,10 @@ static int launch_one(const MlpPlan &p, const void *tiles, const float *x, int M
         cus = 256;
     const int n_pass = zest_div_up(zest_div_up(M, 16 * mlp_cb(EP)), kMlpWaves);
     const int blocks = n_pass < cus ? n_pass : cus;             // one workgroup per CU (128 KiB ring)
-    hipLaunchKernelGGL((mlp_engine_kernel<EP, NT_PTS, MOD, NT_FEAT>), dim3(blocks), dim3(kMlpWaves * 64), 0, stream,
+    hipLaunchKernelGGL((mlp_engine_kernel<EP, NT_PTS, MOD, NT_FEAT, TRAIN>), dim3(blocks), dim3(kMlpWaves * 64), 0, stream,
                        (const uint4 *)tiles, x, M, d.in_ch_pts, F, C_in, C_out, d.head,
-                       d.net_type >= 2 ? 1 : 0, d.net_type == 2 ? 1 : 0, out);
-    ZEST_RETURN_LAUNCH("zest_mlp_fwd(engine)");
+                       d.net_type >= 2 ? 1 : 0, d.net_type == 2 ? 1 : 0, out, (uint4 *)stash_tiles, (uint2 *)stash_masks);
+    ZEST_RETURN_LAUNCH(TRAIN ? "zest_mlp_train16_fwd" : "zest_mlp_fwd(engine)");
 }
 
 template <int EP>
@@ -184,6 +170,25 @@ static int launch_prec(const MlpPlan &p, const void *tiles, const float *x, int 
     }
     zest_set_error("zest_mlp_fwd(engine): no kernel for %d point units / %d feature units per row "
                    "block (supported: 1..14 source views)", p.nt_pts, mod ? p.nt_feat : 0);
+    return (int)hipErrorInvalidValue;
+}
+
+// bf16 training forward: the same kernel with the activation stash (mlp_train16.hip)
+int mlp_engine_train_launch(const MlpPlan &p, const void *tiles, const float *x, int M, float *out, void *stash_tiles,
+                            void *stash_masks, hipStream_t stream) {
+    constexpr int EP = ZEST_PREC_BF16;
+    const bool mod = p.desc.use_feat != 0;
+    const int key = p.nt_pts * 10 + (mod ? p.nt_feat : 0);
+    switch (key) {
+        case 40: return launch_one<EP, 4, false, 0, true>(p, tiles, x, M, out, stream, stash_tiles, stash_masks);
+        case 42: return launch_one<EP, 4, true, 2, true>(p, tiles, x, M, out, stream, stash_tiles, stash_masks);
+        case 44: return launch_one<EP, 4, true, 4, true>(p, tiles, x, M, out, stream, stash_tiles, stash_masks);
+        case 60: return launch_one<EP, 6, false, 0, true>(p, tiles, x, M, out, stream, stash_tiles, stash_masks);
+        case 62: return launch_one<EP, 6, true, 2, true>(p, tiles, x, M, out, stream, stash_tiles, stash_masks);
+        case 64: return launch_one<EP, 6, true, 4, true>(p, tiles, x, M, out, stream, stash_tiles, stash_masks);
+    }
+    zest_set_error("zest_mlp_train16_fwd: no kernel for %d point units / %d feature units per row block", p.nt_pts,
+                   mod ? p.nt_feat : 0);
     return (int)hipErrorInvalidValue;
 }
 

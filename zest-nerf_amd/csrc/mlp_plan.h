@@ -103,6 +103,42 @@ inline bool prec_is_engine(int precision) {     // the register engine's operand
     return precision == ZEST_PREC_BF16 || precision == ZEST_PREC_F16 || precision == ZEST_PREC_F16X3;
 }
 
+// ---- bf16 training path (mlp_train16.hip) ---------------------------------------------------
+// Backward-data stream: the transposed weights in the order the backward walk consumes them
+// (rgb, view layer, feature_linear + heads, trunk layers 7 .. 0), same unit format as the forward
+// ORDER_ACC stream: per row block of 32 INPUT features a header (bias block zero, modulation bias
+// block of the layer whose ReLU mask / modulation the epilogue applies), its modulation tiles, then
+// per k-tile of OUTPUT-feature positions the row tiles 0, 1.  Built into an MlpPlan so the forward
+// packer packs it (tile_src / hdr_src / n_tiles / bytes are the fields used).
+bool build_bwd_plan(const zest_mlp_desc &d, MlpPlan *out, const char **err);
+// row blocks / k-tiles of the backward ops, shared by the plan builder and the kernel's unrolled walk
+constexpr int bwd_stream_units_raw(int nt_pts, int nt_feat) {
+    const int kp = nt_pts / 2, mod = nt_feat;       // pts k-tiles; modulation units per row block (0 = off)
+    return 4 * (1 + 2 * 1)                          // rgb^T: 4 row blocks (128 view-layer features) x 1 k-tile
+           + 8 * (1 + 2 * 4)                        // view layer^T: 8 row blocks (feature_linear outputs) x 4 k-tiles
+           + 8 * (1 + mod + 2 * 9)                  // feature_linear^T | heads^T: -> d h7, masked + modulated as layer 7
+           + 6 * 8 * (1 + mod + 2 * 8)              // layers 7, 6, 4, 3, 2, 1 -> d h(l-1)
+           + kp * (1 + 2 * 8) + 8 * (1 + mod + 2 * 8)   // layer 5: point rows, then d h4
+           + kp * (1 + 2 * 8);                      // layer 0: point rows
+}
+constexpr int bwd_stream_units(int nt_pts, int nt_feat) {
+    return (bwd_stream_units_raw(nt_pts, nt_feat) + kStreamAlign - 1) / kStreamAlign * kStreamAlign;
+}
+
+// One weight-gradient job of the training path: (op's output positions) x (a chunk of <= 256 input positions)
+struct DwJob {
+    int32_t out_tile0, n_out_tiles;      // gradient-stash tiles (k-tiles of 32 output positions)
+    int32_t in_kind;                     // 0: activation-stash tiles, 1: point operand (from x), 2: feature operand, 3: direction operand
+    int32_t in_tile0, n_in_tiles;
+    int32_t ld, col0, want_bias;
+    int16_t out_slot[256], out_row[256]; // output position -> (ZEST_P_* slot, row of its weight), -1: none
+    int16_t in_col[256];                 // input position -> column (before col0), -1: none
+};
+// stash tile indices of the gradient stash (work buffer): d pre-activation of trunk layer l: 8 l + kt;
+// feature_linear 64 + kt; view layer 72 + kt; head tile 76; rgb tile 77; modulation 78 + kt
+constexpr int kGradTiles = 86;
+int build_dw_jobs(const zest_mlp_desc &d, std::vector<DwJob> *jobs, const char **err);
+
 // Builds the plan; returns false (with *err set) for shapes the kernels do not cover.
 // with_tables = false skips the packer's gather tables (cheap: launch-time shape queries).
 bool build_plan(const zest_mlp_desc &d, int precision, int order, MlpPlan *out, const char **err,

@@ -234,4 +234,153 @@ bool build_plan(const zest_mlp_desc &d, int precision, int order, MlpPlan *P, co
     return true;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// bf16 training path: backward-data stream and weight-gradient jobs (see mlp_plan.h)
+namespace {
+
+struct BwdCtx {
+    const zest_mlp_desc &d;
+    MlpPlan &p;
+    int ld[ZEST_P_COUNT];
+    int t = 0;                       // next unit
+    std::vector<uint32_t> tile_src, hdr_src;
+    void grow(int units) {
+        tile_src.resize((size_t)(t + units) * 512, 0xFFFFFFFFu);
+        hdr_src.resize((size_t)(t + units) * 64, 0xFFFFFFFFu);
+    }
+};
+
+// (param slot, row) of output feature `o` of a forward op; op ids as in build_plan (8 = head tile)
+inline RowSrc out_row_of(const zest_mlp_desc &d, int op, int o) {
+    if (op < 8) return {ZEST_P_PTS0 + op, o};
+    if (op == 9) return {ZEST_P_FEATURE, o};
+    if (op == 10) return {o < kW / 2 ? ZEST_P_VIEWS : -1, o};
+    if (op == 11) return {o < 3 ? ZEST_P_RGB : -1, o};
+    if (o == 0) return {ZEST_P_ALPHA, 0};
+    if (d.head == ZEST_HEAD_BLEND && o == 1) return {ZEST_P_HEAD0, 0};
+    if (d.head == ZEST_HEAD_DYNAMIC && o >= 1 && o <= 6) return {ZEST_P_HEAD0, o - 1};
+    if (d.head == ZEST_HEAD_DYNAMIC && o >= 7 && o <= 8) return {ZEST_P_HEAD1, o - 7};
+    return {-1, 0};
+}
+
+// One row block of 32 input indices of a transposed op: header (+ modulation tiles of block `mod_jb`
+// when mod_jb >= 0) + per k-tile of the op's output positions the row tiles 0, 1.
+//   in_col(i): column of input index i (0..31 of this row block) in the op's weight, -1 = zero row
+//   segs: {forward op id, k-tiles of its output positions}
+template <class InCol>
+void emit_bwd_row_block(BwdCtx &c, InCol in_col, int mod_jb, const int (*segs)[2], int nseg) {
+    const MlpPlan &p = c.p;
+    int units = 1 + (mod_jb >= 0 ? p.nt_feat : 0);
+    for (int s = 0; s < nseg; s++) units += 2 * segs[s][1];
+    c.grow(units);
+    // header: accumulator initialiser 0; modulation bias block of block mod_jb
+    if (mod_jb >= 0)
+        for (int i = 0; i < 32; i++)
+            c.hdr_src[(size_t)c.t * 64 + 32 + i] = ((uint32_t)ZEST_P_PTS_BIAS << 24) | (uint32_t)(32 * mod_jb + i);
+    c.t++;
+    if (mod_jb >= 0)
+        for (int k = 0; k < p.nt_feat; k++, c.t++)
+            for (int l = 0; l < 64; l++)
+                for (int e = 0; e < 8; e++) {
+                    const int pos = (k / 2) * 32 + 8 * (l >> 4) + e, row = 32 * mod_jb + 16 * (k % 2) + (l & 15);
+                    const int feat = p.map_feat[pos];
+                    if (feat < 0) continue;
+                    c.tile_src[((size_t)c.t * 64 + l) * 8 + e] =
+                        ((uint32_t)ZEST_P_PTS_BIAS << 24) | (uint32_t)(row * c.ld[ZEST_P_PTS_BIAS] + feat);
+                }
+    for (int s = 0; s < nseg; s++)
+        for (int k = 0; k < 2 * segs[s][1]; k++, c.t++)
+            for (int l = 0; l < 64; l++)
+                for (int e = 0; e < 8; e++) {
+                    const int pos = (k / 2) * 32 + 8 * (l >> 4) + e;            // position of the op's output operand
+                    const int o = h_feature(ORDER_ACC, 8, pos, 0);               // ... is this output feature
+                    const RowSrc rs = out_row_of(c.d, segs[s][0], o);
+                    const int col = in_col(16 * (k % 2) + (l & 15));
+                    if (rs.param < 0 || col < 0) continue;
+                    c.tile_src[((size_t)c.t * 64 + l) * 8 + e] =
+                        ((uint32_t)rs.param << 24) | (uint32_t)(rs.row * c.ld[rs.param] + col);
+                }
+}
+
+}  // namespace
+
+bool build_bwd_plan(const zest_mlp_desc &d, MlpPlan *P, const char **err) {
+    if (!build_plan(d, ZEST_PREC_BF16, ORDER_ACC, P, err, false)) return false;
+    if (d.net_type != 0) return *err = "the bf16 training path covers 'v0' nets", false;
+    MlpPlan &p = *P;
+    BwdCtx c{d, p, {d.in_ch_pts, kW, kW, kW, kW, kW + d.in_ch_pts, kW, kW, d.in_ch_feat, kW + d.in_ch_views, kW, kW,
+                    kW / 2, kW, kW}};
+    const bool mod = d.use_feat != 0;
+    const int kp = p.nt_pts / 2;
+    auto natural = [](int base) { return [base](int i) { return base + i; }; };
+    // 1. rgb^T: rows = the 128 view-layer features
+    for (int jb = 0; jb < 4; jb++) { const int sg[1][2] = {{11, 1}}; emit_bwd_row_block(c, natural(32 * jb), -1, sg, 1); }
+    // 2. view layer^T: rows = feature_linear outputs (columns 0..255 of views_linears.0)
+    for (int jb = 0; jb < 8; jb++) { const int sg[1][2] = {{10, 4}}; emit_bwd_row_block(c, natural(32 * jb), -1, sg, 1); }
+    // 3. feature_linear^T | head^T: rows = h7; the epilogue applies layer 7's mask and modulation
+    for (int jb = 0; jb < 8; jb++) { const int sg[2][2] = {{9, 8}, {8, 1}}; emit_bwd_row_block(c, natural(32 * jb), mod ? jb : -1, sg, 2); }
+    // 4. trunk layers 7 .. 1: rows = inputs of layer l (layer 5: the point positions first), epilogue of layer l-1
+    for (int l = 7; l >= 1; l--) {
+        const int sg[1][2] = {{l, 8}};
+        if (l == 5)
+            for (int jb = 0; jb < kp; jb++)
+                emit_bwd_row_block(c, [&](int i) { return (int)p.map_pts[32 * jb + i]; }, -1, sg, 1);
+        const int h0 = l == 5 ? d.in_ch_pts : 0;         // columns of the hidden part
+        for (int jb = 0; jb < 8; jb++) emit_bwd_row_block(c, natural(h0 + 32 * jb), mod ? jb : -1, sg, 1);
+    }
+    // 5. layer 0: rows = the point positions
+    for (int jb = 0; jb < kp; jb++) {
+        const int sg[1][2] = {{0, 8}};
+        emit_bwd_row_block(c, [&](int i) { return (int)p.map_pts[32 * jb + i]; }, -1, sg, 1);
+    }
+    if (c.t != bwd_stream_units_raw(p.nt_pts, mod ? p.nt_feat : 0)) return *err = "backward stream: unit count mismatch", false;
+    const int total = round_up(c.t, kStreamAlign);
+    c.grow(total - c.t);
+    p.headers = 1, p.parts = 1, p.n_tiles = total, p.n_bias_blocks = 0, p.bias_bytes = 0;
+    p.bytes = (size_t)total * 1024;
+    p.tile_src.swap(c.tile_src), p.hdr_src.swap(c.hdr_src);
+    p.bias_src.clear();
+    p.unit_part.assign((size_t)total, 0);
+    return true;
+}
+
+int build_dw_jobs(const zest_mlp_desc &d, std::vector<DwJob> *jobs, const char **err) {
+    MlpPlan p;
+    if (!build_plan(d, ZEST_PREC_BF16, ORDER_ACC, &p, err, false)) return -1;
+    jobs->clear();
+    const bool mod = d.use_feat != 0;
+    const int kp = p.nt_pts / 2, kf = p.nt_feat / 2;
+    auto add = [&](int op, int out_tile0, int n_out, int in_kind, int in_tile0, int n_in, int ld, int col0, int bias,
+                   const std::vector<int16_t> *in_map) {
+        DwJob j;
+        memset(&j, 0, sizeof(j));
+        j.out_tile0 = out_tile0, j.n_out_tiles = n_out, j.in_kind = in_kind, j.in_tile0 = in_tile0, j.n_in_tiles = n_in;
+        j.ld = ld, j.col0 = col0, j.want_bias = bias;
+        for (int pos = 0; pos < 256; pos++) {
+            j.out_slot[pos] = -1, j.out_row[pos] = 0, j.in_col[pos] = -1;
+            if (pos < 32 * n_out) {
+                const int o = h_feature(ORDER_ACC, 8, pos, 0);
+                const RowSrc rs = op == 100 ? RowSrc{ZEST_P_PTS_BIAS, o} : out_row_of(d, op, o);
+                j.out_slot[pos] = (int16_t)rs.param, j.out_row[pos] = (int16_t)rs.row;
+            }
+            if (pos < 32 * n_in)
+                j.in_col[pos] = in_map ? (*in_map)[pos] : (int16_t)h_feature(ORDER_ACC, 8, pos, 0);
+        }
+        jobs->push_back(j);
+    };
+    for (int l = 0; l < 8; l++) {
+        const int ld = l == 0 ? d.in_ch_pts : (l == 5 ? kW + d.in_ch_pts : kW);
+        if (l == 0 || l == 5) add(l, 8 * l, 8, 1, 0, kp, ld, 0, l == 0, &p.map_pts);
+        if (l > 0) add(l, 8 * l, 8, 0, 8 * (l - 1), 8, ld, l == 5 ? d.in_ch_pts : 0, 1, nullptr);
+    }
+    add(8, 76, 1, 0, 56, 8, kW, 0, 1, nullptr);                       // heads <- h7
+    add(9, 64, 8, 0, 56, 8, kW, 0, 1, nullptr);                       // feature_linear <- h7
+    add(10, 72, 4, 0, 64, 8, kW + d.in_ch_views, 0, 1, nullptr);      // view layer <- feature_linear output
+    add(10, 72, 4, 3, 0, 1, kW + d.in_ch_views, kW, 0, &p.map_views); //            <- direction encoding
+    add(11, 77, 1, 0, 72, 4, kW / 2, 0, 1, nullptr);                  // rgb <- view layer
+    if (mod) add(100, 78, 8, 2, 0, kf, d.in_ch_feat, 0, 1, &p.map_feat);   // pts_bias <- features
+    return (int)jobs->size();
+}
+
 }  // namespace zest

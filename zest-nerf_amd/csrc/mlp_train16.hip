@@ -1,0 +1,639 @@
+// bf16 training path of the width-256 MLP on the register engine (consumer:
+// reference train.py:587-760 -> backward through Renderer.forward, networks.py:150-221).
+//
+// Forward = the inference engine kernel with an activation stash (mlp_engine.hip, TRAIN).  Backward =
+// three kernels, none of which materialises a [samples x 256] fp32 tensor:
+//   data kernel     the backward walk on the SAME register engine with the transposed weight stream
+//                   (mlp_plan.hip build_bwd_plan): a wave carries the gradient of its 32 samples through
+//                   rgb -> view layer -> feature_linear | heads -> trunk 7 .. 0 in registers; every
+//                   transposed GEMM's epilogue applies the ReLU mask (one bit per element, stashed by the
+//                   forward) and the modulation m = pts_bias(feats) (recomputed per row block with the
+//                   same 2-4 MFMA pairs as the forward) and leaves d(pre-activation) as the next
+//                   operand; those tiles also go to the gradient stash; the point-encoding rows of
+//                   layers 5 and 0 leave as float atomics into g_x.
+//   modulation      d m = sum_l d pre_l * h_l / m^2 per sample from the two stashes, d features = Wm^T d m.
+//   weight kernel   d W_op = sum over samples of d pre_op (x) input_op, d b_op = sum d pre_op: stash tiles
+//                   hold samples on the lane axis, the contraction runs over samples, so the tiles are
+//                   staged in LDS and read back with the transposing LDS read (ds_read_b64_tr_b16) as
+//                   MFMA operands with k = sample; a wave keeps a 32 x 256 slice of d W in registers over
+//                   all the blocks of its workgroup and adds it to the fp32 gradient once.
+#include <string.h>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+#include "mlp_operands.cuh"
+#include "mlp_train16.h"
+
+namespace zest {
+size_t bwd_stream_bytes(const zest_mlp_desc &d);
+int bwd_stream_units_of(const zest_mlp_desc &d);
+int pack_bwd_stream(const zest_mlp_desc &d, const float *const *params, void *packed, hipStream_t stream);
+int mlp_engine_train_launch(const MlpPlan &p, const void *tiles, const float *x, int M, float *out, void *stash_tiles,
+                            void *stash_masks, hipStream_t stream);
+}  // namespace zest
+
+namespace {
+
+using namespace zest;
+constexpr int EP = ZEST_PREC_BF16;
+constexpr int kWaves = 8;
+
+struct Sizes {
+    long long blocks;
+    size_t tile_bytes, mask_bytes, grad_bytes;
+};
+Sizes sizes_of(int M) {
+    Sizes s;
+    s.blocks = train_blocks(M);
+    s.tile_bytes = (size_t)s.blocks * kStashTiles * 2 * 1024;
+    s.mask_bytes = (size_t)s.blocks * kStashMasks * 2 * 64 * 8;
+    s.grad_bytes = (size_t)s.blocks * kGradTiles * 2 * 1024;
+    return s;
+}
+
+__device__ __forceinline__ void unpack8(const uint4 q, float (&v)[8]) {
+    const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[2 * i] = __uint_as_float(w[i] << 16), v[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
+    return make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+}
+
+// ------------------------------------------------------------------------------ data kernel
+// One transposed Linear: NJB row blocks of 32 INPUT indices over the operand [A (NKA k-tiles) | B (NKB)] of
+// output-feature positions.  MOD: the row block also computes m (header modulation bias + NKF feature
+// k-tiles).  MODE 0: epi.tile(jb, cb, v, m) finishes the 8 values (mask, modulation), which become k-tile jb
+// of `out`;  MODE 2: epi.rows(jb, cb, v) takes the raw sums (point-encoding gradients).
+template <int CB, int NJB, int NKA, int NKB, bool MOD, int NKF, int MODE, class Tiles, class Epi>
+__device__ __forceinline__ void bwd_layer(const Tiles &tiles, int &unit, const OpArr<NKA> (&opa)[CB],
+                                          const OpArr<NKB> (&opb)[CB], const OpArr<NKF> (&opf)[CB],
+                                          OpArr<8> (&out)[CB], const Epi &epi) {
+    constexpr int NM = MOD ? 2 * NKF : 0, T = NM + 2 * (NKA + NKB);
+    struct Pre {
+        f32x4 mbias[2];
+        bf16x8 win[kPrefetch];
+    };
+    auto preload = [&](Pre &p, int u0) {
+        tiles.touch(u0);                                         // the header unit: walked exactly once
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++)
+            if (MOD) p.mbias[rt] = tiles.load_bias(u0, 1, rt);
+#pragma unroll
+        for (int k = 0; k < kPrefetch; k++)
+            if (k < T) p.win[k] = tiles.load(u0 + 1 + k);
+    };
+    Pre pre;
+    preload(pre, unit);
+#pragma unroll
+    for (int jb = 0; jb < NJB; jb++) {
+        const int u0 = unit;
+        f32x4 acc[2][CB], macc[2][CB];
+        bf16x8 win[kPrefetch];
+#pragma unroll
+        for (int k = 0; k < kPrefetch; k++) win[k] = pre.win[k];
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+            for (int cb = 0; cb < CB; cb++) {
+                acc[rt][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (MOD) macc[rt][cb] = pre.mbias[rt];
+            }
+#pragma unroll
+        for (int k = 0; k < T; k++) {
+            const bf16x8 a = win[k % kPrefetch];
+            const int rt = k % 2, kt = (k < NM ? k : k - NM) / 2;
+#pragma unroll
+            for (int cb = 0; cb < CB; cb++) {
+                if (k < NM)
+                    macc[rt][cb] = mfma16<EP>(a, opf[cb].t[0][k < NM ? kt : 0], macc[rt][cb]);
+                else if (kt < NKA)
+                    acc[rt][cb] = mfma16<EP>(a, opa[cb].t[0][(k >= NM && kt < NKA) ? kt : 0], acc[rt][cb]);
+                else
+                    acc[rt][cb] = mfma16<EP>(a, opb[cb].t[0][(k >= NM && kt >= NKA) ? kt - NKA : 0], acc[rt][cb]);
+            }
+            if (k + kPrefetch < T) win[k % kPrefetch] = tiles.load(u0 + 1 + k + kPrefetch);
+        }
+        unit = u0 + 1 + T;
+        if (jb + 1 < NJB) preload(pre, unit);
+#pragma unroll
+        for (int cb = 0; cb < CB; cb++) {
+            float v[8], m[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = acc[i >> 2][cb][i & 3], m[i] = MOD ? macc[i >> 2][cb][i & 3] : 1.0f;
+            if (MODE == 0) {
+                epi.tile(jb, cb, v, m);
+                store_tile<EP>(v, out[cb], jb);
+            } else {
+                epi.rows(jb, cb, v);
+            }
+        }
+    }
+}
+
+// epilogue of a transposed GEMM whose result is d h of a masked (and modulated) layer
+template <int CB>
+struct MaskEpi {
+    uint4 *grad;            // gradient stash tiles of this block: [kGradTiles][CB][64]
+    int tile0, lane;
+    unsigned lo[CB], hi[CB];
+    bool masked;
+    __device__ __forceinline__ void tile(int jb, int cb, float (&v)[8], const float (&m)[8]) const {
+        const unsigned bits = masked ? ((jb < 4 ? lo[cb] >> (8 * jb) : hi[cb] >> (8 * (jb - 4))) & 0xFFu) : 0xFFu;
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = ((bits >> i) & 1u) ? v[i] * m[i] : 0.0f;
+        grad[((tile0 + jb) * CB + cb) * 64 + lane] = pack8(v);
+    }
+    __device__ __forceinline__ void rows(int, int, const float (&)[8]) const {}
+};
+
+// point-encoding rows: row 16 rt + 4 g + r of row block jb is operand position 32 jb + that; its column in x
+// comes from the position map (kept in LDS)
+template <int CB>
+struct PtsEpi {
+    float *gx[CB];          // g_x row of this lane's sample in each column block (nullptr: past M)
+    const short *map;       // LDS: position -> column of the point encoding, -1 none
+    int grp;
+    __device__ __forceinline__ void tile(int, int, float (&)[8], const float (&)[8]) const {}
+    __device__ __forceinline__ void rows(int jb, int cb, const float (&v)[8]) const {
+        if (!gx[cb]) return;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int pos = 32 * jb + 16 * (i >> 2) + 4 * grp + (i & 3), col = map[pos];
+            if (col >= 0) atomicAdd(gx[cb] + col, v[i]);
+        }
+    }
+};
+
+template <int NT_PTS, bool MOD, int NT_FEAT>
+__global__ __launch_bounds__(kWaves * 64, kWaves / 4) void train16_data_kernel(
+    const uint4 *__restrict__ stream, const float *__restrict__ x, const float *__restrict__ out,
+    const float *__restrict__ g_out, int M, int P, int F, int C_in, int C_out, int head,
+    const uint2 *__restrict__ masks, const short *__restrict__ map_pts_g, uint4 *__restrict__ grad,
+    float *__restrict__ g_x) {
+    constexpr int CB = 2, KP = NT_PTS / 2, KF = NT_FEAT / 2;
+    constexpr int UNITS = bwd_stream_units(NT_PTS, MOD ? NT_FEAT : 0);
+    using Ring = RingTiles<kWaves, UNITS, 0>;
+    __shared__ __attribute__((aligned(16))) char lds[kRingUnits * 1024 + 2 * kSlots * 4 + 96 * 2];
+    short *map_pts = reinterpret_cast<short *>(lds + kRingUnits * 1024 + 2 * kSlots * 4);
+    if (threadIdx.x < 32 * KP) map_pts[threadIdx.x] = map_pts_g[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, col = lane & 15, grp = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const Ring tiles{lds, (gptr_u4)stream, (gptr_u4)stream, lane, grp, wave,
+                     (unsigned)(wave * Ring::kPieces * 64 + lane) * 16u,
+                     (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds + (unsigned)wave * Ring::kPieces * 1024u};
+    tiles.init_addr();
+    tiles.prologue();
+    const long long n_blocks = ((long long)M + 31) / 32, n_pass = (n_blocks + kWaves - 1) / kWaves;
+    for (long long pass = blockIdx.x; pass < n_pass; pass += gridDim.x) {
+        const long long block = pass * kWaves + wave;
+        const long long m_base = block * 32;
+        uint4 *gblk = grad + (size_t)block * kGradTiles * CB * 64;
+        const uint2 *mblk = masks + (size_t)block * kStashMasks * CB * 64;
+        OpArr<1> d_rgb[CB], d_head[CB];
+        OpArr<KF> feat[CB];
+        OpArr<0> none[CB];
+        float *gx_row[CB];
+        // ---- gradients of the raw network outputs from g_out (activation derivatives through `out`)
+#pragma unroll
+        for (int cb = 0; cb < CB; cb++) {
+            const long long m = m_base + 16 * cb + col;
+            const bool valid = m < M;
+            const float *go = g_out + (size_t)(valid ? m : 0) * C_out, *o = out + (size_t)(valid ? m : 0) * C_out;
+            gx_row[cb] = valid ? g_x + (size_t)m * C_in : nullptr;
+            float r[8] = {0, 0, 0, 0, 0, 0, 0, 0}, h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (valid) {
+                if (grp == 0) {
+                    r[0] = go[0], r[1] = go[1], r[2] = go[2];                   // 'v0': rgb and alpha are raw
+                    h[0] = go[3];
+                    if (head == ZEST_HEAD_BLEND) h[1] = go[4] * o[4] * (1.0f - o[4]);
+                    if (head == ZEST_HEAD_DYNAMIC)
+                        for (int i = 1; i < 4; i++) h[i] = go[3 + i] * (1.0f - o[3 + i] * o[3 + i]);     // tanh rows 1-3
+                } else if (head == ZEST_HEAD_DYNAMIC && grp == 1) {
+                    for (int i = 0; i < 3; i++) h[i] = go[7 + i] * (1.0f - o[7 + i] * o[7 + i]);         // tanh rows 4-6
+                    h[3] = go[10] * o[10] * (1.0f - o[10]);                                              // sigmoid row 7
+                } else if (head == ZEST_HEAD_DYNAMIC && grp == 2) {
+                    h[0] = go[11] * o[11] * (1.0f - o[11]);                                              // sigmoid row 8
+                }
+            }
+            store_tile<EP>(r, d_rgb[cb], 0);
+            store_tile<EP>(h, d_head[cb], 0);
+            gblk[(76 * CB + cb) * 64 + lane] = __builtin_bit_cast(uint4, d_head[cb].t[0][0]);
+            gblk[(77 * CB + cb) * 64 + lane] = __builtin_bit_cast(uint4, d_rgb[cb].t[0][0]);
+            if (MOD) load_feat_operand<EP, KF>(x + (size_t)(valid ? m : 0) * C_in + P, F, valid, grp, feat[cb]);
+        }
+        auto mask_epi = [&](int mask_id, int tile0) {
+            MaskEpi<CB> e;
+            e.grad = gblk, e.tile0 = tile0, e.lane = lane, e.masked = mask_id >= 0;
+#pragma unroll
+            for (int cb = 0; cb < CB; cb++) {
+                const uint2 w = mask_id >= 0 ? mblk[(mask_id * CB + cb) * 64 + lane] : make_uint2(0, 0);
+                e.lo[cb] = w.x, e.hi[cb] = w.y;
+            }
+            return e;
+        };
+        int unit = 0;
+        OpArr<8> ga[CB], gb[CB];
+        // 1. rgb^T -> d view-layer output, masked by the view layer's ReLU (4 k-tiles)
+        bwd_layer<CB, 4, 1, 0, false, KF, 0>(tiles, unit, d_rgb, none, feat, ga, mask_epi(8, 72));
+        OpArr<4> g_hv[CB];
+#pragma unroll
+        for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) g_hv[cb].t[0][k] = ga[cb].t[0][k];
+        // 2. view layer^T -> d feature_linear output (no activation)
+        bwd_layer<CB, 8, 4, 0, false, KF, 0>(tiles, unit, g_hv, none, feat, gb, mask_epi(-1, 64));
+        // 3. feature_linear^T | heads^T -> d h7, masked and modulated as layer 7 -> d pre_7
+        bwd_layer<CB, 8, 8, 1, MOD, KF, 0>(tiles, unit, gb, d_head, feat, ga, mask_epi(7, 56));
+        // 4. trunk layers 7 .. 1 (layer 5: the point rows first)
+        PtsEpi<CB> pe;
+        pe.map = map_pts, pe.grp = grp;
+#pragma unroll
+        for (int cb = 0; cb < CB; cb++) pe.gx[cb] = gx_row[cb];
+        bwd_layer<CB, 8, 8, 0, MOD, KF, 0>(tiles, unit, ga, none, feat, gb, mask_epi(6, 48));     // layer 7 -> d pre_6
+        bwd_layer<CB, 8, 8, 0, MOD, KF, 0>(tiles, unit, gb, none, feat, ga, mask_epi(5, 40));     // layer 6 -> d pre_5
+        bwd_layer<CB, KP, 8, 0, false, KF, 2>(tiles, unit, ga, none, feat, gb, pe);                // layer 5: points
+        bwd_layer<CB, 8, 8, 0, MOD, KF, 0>(tiles, unit, ga, none, feat, gb, mask_epi(4, 32));     // layer 5 -> d pre_4
+        bwd_layer<CB, 8, 8, 0, MOD, KF, 0>(tiles, unit, gb, none, feat, ga, mask_epi(3, 24));     // layer 4 -> d pre_3
+        bwd_layer<CB, 8, 8, 0, MOD, KF, 0>(tiles, unit, ga, none, feat, gb, mask_epi(2, 16));     // layer 3 -> d pre_2
+        bwd_layer<CB, 8, 8, 0, MOD, KF, 0>(tiles, unit, gb, none, feat, ga, mask_epi(1, 8));      // layer 2 -> d pre_1
+        bwd_layer<CB, 8, 8, 0, MOD, KF, 0>(tiles, unit, ga, none, feat, gb, mask_epi(0, 0));      // layer 1 -> d pre_0
+        bwd_layer<CB, KP, 8, 0, false, KF, 2>(tiles, unit, gb, none, feat, ga, pe);                // layer 0: points
+        tiles.finish(unit, UNITS);
+        tiles.next_pass();
+    }
+    tiles.drain();
+}
+
+// ------------------------------------------------------------------------------ modulation kernel
+// d m [sample][256] = sum over the 8 trunk layers of d pre_l * h_l / m^2 (d pre_l = d h_l mask m, h_l = pre_l m:
+// the product is d h_l mask pre_l), written as gradient-stash tiles 78 .. 85; d features = Wm^T d m into g_x.
+// One wave per block of 32 samples, everything from global memory / L2 (no ring): m is recomputed with
+// the forward's modulation tiles (fwd stream), Wm^T tiles come from the backward stream's row blocks.
+template <int NT_FEAT>
+__global__ __launch_bounds__(256) void train16_mod_kernel(const float *__restrict__ x, int M, int P, int F, int C_in,
+                                                           const float *__restrict__ wm, const float *__restrict__ bm,
+                                                           const uint4 *__restrict__ stash, uint4 *__restrict__ grad,
+                                                           const short *__restrict__ map_feat, float *__restrict__ g_x) {
+    constexpr int CB = 2, KF = NT_FEAT / 2;
+    const int lane = threadIdx.x & 63, col = lane & 15, grp = lane >> 4;
+    const long long block = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (block * 32 >= M) return;
+    const uint4 *sblk = stash + (size_t)block * kStashTiles * CB * 64;
+    uint4 *gblk = grad + (size_t)block * kGradTiles * CB * 64;
+    float fvals[CB][KF * 8];       // this lane's feature values (operand positions), fp32
+    bool valid[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; cb++) {
+        const long long m = block * 32 + 16 * cb + col;
+        valid[cb] = m < M;
+        const float *xf = x + (size_t)(valid[cb] ? m : 0) * C_in + P;
+#pragma unroll
+        for (int t = 0; t < KF; t++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int c = map_feat[32 * t + 8 * grp + e];
+                fvals[cb][8 * t + e] = (valid[cb] && c >= 0) ? xf[c] : 0.0f;
+            }
+    }
+    // Each lane needs m and accumulates d m for the 8 features (4g..4g+3, 16+4g..) of every block of 32: the
+    // features of operand position 8g+e.  Every lane (col, g) holds the feature values of positions 8g..8g+7 of
+    // its sample only, so m = Wm f needs the other groups' values: gather them with lane shuffles.
+#pragma unroll 1
+    for (int cb = 0; cb < CB; cb++) {
+        float fall[KF * 32];       // all feature positions of this lane's sample
+#pragma unroll
+        for (int t = 0; t < KF; t++)
+#pragma unroll
+            for (int gsrc = 0; gsrc < 4; gsrc++)
+#pragma unroll
+                for (int e = 0; e < 8; e++)
+                    fall[32 * t + 8 * gsrc + e] = __shfl(fvals[cb][8 * t + e], col + 16 * gsrc, 64);
+        float dall[KF * 32];       // d feature positions: every group adds its 64 features' share
+#pragma unroll
+        for (int i = 0; i < KF * 32; i++) dall[i] = 0.0f;
+#pragma unroll 1
+        for (int jb = 0; jb < 8; jb++) {
+            float mval[8], dm[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int f = 32 * jb + (e < 4 ? 4 * grp + e : 16 + 4 * grp + (e - 4));
+                float a = bm[f];
+                const float *wr = wm + (size_t)f * F;
+                for (int t = 0; t < KF; t++)
+                    for (int q = 0; q < 32; q++) {
+                        const int c = map_feat[32 * t + q];
+                        if (c >= 0) a = fmaf(wr[c], fall[32 * t + q], a);
+                    }
+                mval[e] = a, dm[e] = 0.0f;
+            }
+            for (int l = 0; l < 8; l++) {
+                float dp[8], hv[8];
+                unpack8(gblk[((8 * l + jb) * CB + cb) * 64 + lane], dp);
+                unpack8(sblk[((8 * l + jb) * CB + cb) * 64 + lane], hv);
+#pragma unroll
+                for (int e = 0; e < 8; e++) dm[e] += hv[e] != 0.0f ? dp[e] * hv[e] / (mval[e] * mval[e]) : 0.0f;
+            }
+            gblk[((78 + jb) * CB + cb) * 64 + lane] = pack8(dm);
+            // d features: d f[c] += sum over this lane's 8 features of Wm[f][c] d m[f]
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int f = 32 * jb + (e < 4 ? 4 * grp + e : 16 + 4 * grp + (e - 4));
+                const float *wr = wm + (size_t)f * F;
+                for (int t = 0; t < KF; t++)
+                    for (int q = 0; q < 32; q++) {
+                        const int c = map_feat[32 * t + q];
+                        if (c >= 0) dall[32 * t + q] = fmaf(wr[c], dm[e], dall[32 * t + q]);
+                    }
+            }
+        }
+        // sum the four groups' shares (lanes col, col+16, col+32, col+48) and write the sample's feature columns
+#pragma unroll
+        for (int i = 0; i < KF * 32; i++) {
+            float s = dall[i];
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            dall[i] = s;
+        }
+        if (valid[cb] && grp == 0) {
+            float *go = g_x + (size_t)(block * 32 + 16 * cb + col) * C_in + P;
+            for (int i = 0; i < KF * 32; i++) {
+                const int c = map_feat[i];
+                if (c >= 0) go[c] = dall[i];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ weight kernel
+constexpr int kImgStride = 528;              // bytes per sample row of an LDS image: 256 positions x 2 B + 16 (bank spread)
+constexpr int kImgBytes = 32 * kImgStride;
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+// operand with k = the 32 samples of a block: rows/cols = positions p0 .. p0+15 of the image
+__device__ __forceinline__ bf16x8 tr_operand(unsigned img_addr, int p0, int lane) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const unsigned a = img_addr + (unsigned)(8 * g + q) * kImgStride + (unsigned)(p0 + 4 * p) * 2u;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(uintptr_t)a);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(uintptr_t)(a + 4 * kImgStride));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+__global__ __launch_bounds__(kWaves * 64, kWaves / 4) void train16_dw_kernel(
+    const DwJob *__restrict__ jobs, int wg_per_job, const uint4 *__restrict__ stash, const uint4 *__restrict__ grad,
+    const float *__restrict__ x, int M, int P, int F, int C_in, int pts_c, float *const *__restrict__ g_params) {
+    constexpr int CB = 2;
+    __shared__ __attribute__((aligned(16))) char img[2][2][kImgBytes];      // [buffer][0: out (gradient), 1: in][...]
+    const DwJob &job = jobs[blockIdx.x / wg_per_job];
+    const int part = blockIdx.x % wg_per_job;
+    const int lane = threadIdx.x & 63, col = lane & 15, grp = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long n_blocks = ((long long)M + 31) / 32;
+    const long long per = (n_blocks + wg_per_job - 1) / wg_per_job;
+    const long long b0 = part * per, b1 = min(n_blocks, b0 + per);
+    const int n_in = job.n_in_tiles, n_out = job.n_out_tiles;
+    f32x4 acc[2][16], accb[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++) {
+        accb[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ct = 0; ct < 16; ct++) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    const unsigned img0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)&img[0][0][0];
+    for (long long b = b0; b < b1; b++) {
+        const int buf = (int)((b - b0) & 1);
+        char *im_out = img[buf][0], *im_in = img[buf][1];
+        // ---- stage the block's tiles: items = (tile, column block); image row = sample, 16 B at position 8 g of the k-tile
+        const int items = (n_out + (job.in_kind == 0 ? n_in : 0)) * CB;
+        for (int it = wave; it < items; it += kWaves) {
+            const int t = it / CB, cb = it % CB;
+            const bool is_out = t < n_out;
+            const int kt = is_out ? t : t - n_out;
+            const uint4 q = is_out ? grad[(((size_t)b * kGradTiles + job.out_tile0 + kt) * CB + cb) * 64 + lane]
+                                   : stash[(((size_t)b * kStashTiles + job.in_tile0 + kt) * CB + cb) * 64 + lane];
+            *reinterpret_cast<uint4 *>((is_out ? im_out : im_in) + (16 * cb + col) * kImgStride + kt * 64 + grp * 16) = q;
+        }
+        if (job.in_kind != 0 && wave < CB) {            // operands rebuilt from the rows of x: one column block per wave
+            const int cb = wave;
+            const long long m = b * 32 + 16 * cb + col;
+            const bool valid = m < M;
+            const float *xr = x + (size_t)(valid ? m : 0) * C_in;
+            OpArr<3> o3;
+            if (job.in_kind == 1) {
+                if (pts_c == 3) {
+                    OpArr<2> o2;
+                    load_pe_operand<EP, 3, 10, 2>(xr, valid, grp, o2);
+                    o3.t[0][0] = o2.t[0][0], o3.t[0][1] = o2.t[0][1];
+                } else {
+                    load_pe_operand<EP, 4, 10, 3>(xr, valid, grp, o3);
+                }
+            } else if (job.in_kind == 2) {
+                OpArr<2> o2;
+                load_feat_operand<EP, 2>(xr + P, F, valid, grp, o2);
+                o3.t[0][0] = o2.t[0][0], o3.t[0][1] = o2.t[0][1];
+            } else {
+                OpArr<1> o1;
+                load_pe_operand<EP, 3, 4, 1>(xr + P + F, valid, grp, o1);
+                o3.t[0][0] = o1.t[0][0];
+            }
+            for (int kt = 0; kt < n_in; kt++) {
+                const bf16x8 tq = kt == 0 ? o3.t[0][0] : (kt == 1 ? o3.t[0][1] : o3.t[0][2]);
+                *reinterpret_cast<uint4 *>(im_in + (16 * cb + col) * kImgStride + kt * 64 + grp * 16) = __builtin_bit_cast(uint4, tq);
+            }
+        }
+        __syncthreads();
+        if (wave < n_out) {
+            const unsigned a_out = img0 + (unsigned)(buf * 2) * kImgBytes, a_in = a_out + kImgBytes;
+            bf16x8 A[2];
+#pragma unroll
+            for (int rt = 0; rt < 2; rt++) A[rt] = tr_operand(a_out, 32 * wave + 16 * rt, lane);
+#pragma unroll
+            for (int ct = 0; ct < 16; ct++) {
+                if (ct < 2 * n_in) {
+                    const bf16x8 B = tr_operand(a_in, 16 * ct, lane);
+#pragma unroll
+                    for (int rt = 0; rt < 2; rt++) acc[rt][ct] = mfma16<EP>(A[rt], B, acc[rt][ct]);
+                }
+            }
+            if (job.want_bias) {
+#pragma unroll
+                for (int rt = 0; rt < 2; rt++) accb[rt] = mfma16<EP>(A[rt], ones, accb[rt]);
+            }
+        }
+    }
+    if (wave >= n_out) return;
+    // ---- add this workgroup's slice to the fp32 gradients: accumulator (rt, ct): rows = output positions
+    // 32 wave + 16 rt + 4 g + r, column = input position 16 ct + col
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int po = 32 * wave + 16 * rt + 4 * grp + r;
+            const int slot = job.out_slot[po], row = job.out_row[po];
+            if (slot < 0) continue;
+            float *gw = g_params[2 * slot] + (size_t)row * job.ld + job.col0;
+#pragma unroll
+            for (int ct = 0; ct < 16; ct++) {
+                if (ct >= 2 * n_in) continue;
+                const int ci = job.in_col[16 * ct + col];
+                if (ci >= 0) atomicAdd(gw + ci, acc[rt][ct][r]);
+            }
+            if (job.want_bias && col == 0) atomicAdd(g_params[2 * slot + 1] + row, accb[rt][r]);
+        }
+}
+
+// ------------------------------------------------------------------------------ host side
+struct TrainTables {                 // per MLP shape, device resident
+    DwJob *jobs = nullptr;
+    int n_jobs = 0;
+    short *map_pts = nullptr, *map_feat = nullptr;
+    MlpPlan fwd;                     // forward plan (stream size check, operand tile counts)
+};
+std::mutex g_mu;
+std::map<std::tuple<int, int, int, int, int, int>, TrainTables *> g_tables;
+
+TrainTables *tables_for(const zest_mlp_desc &d) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto key = std::make_tuple(d.in_ch_pts, d.use_feat ? d.in_ch_feat : 0, d.in_ch_views, d.use_feat, d.net_type, d.head);
+    auto it = g_tables.find(key);
+    if (it != g_tables.end()) return it->second;
+    const char *err = nullptr;
+    TrainTables *t = new TrainTables();
+    std::vector<DwJob> jobs;
+    if (d.net_type != 0 || !build_plan(d, ZEST_PREC_BF16, ORDER_ACC, &t->fwd, &err, true) ||
+        build_dw_jobs(d, &jobs, &err) < 0) {
+        zest_set_error("zest_mlp_train16: shape not supported: %s", err ? err : "the bf16 training path covers 'v0' nets");
+        delete t;
+        return nullptr;
+    }
+    t->n_jobs = (int)jobs.size();
+    std::vector<short> mp(96, -1), mf(64, -1);
+    for (size_t i = 0; i < t->fwd.map_pts.size() && i < 96; i++) mp[i] = t->fwd.map_pts[i];
+    for (size_t i = 0; i < t->fwd.map_feat.size() && i < 64; i++) mf[i] = t->fwd.map_feat[i];
+    hipError_t e = hipMalloc(&t->jobs, jobs.size() * sizeof(DwJob));
+    if (e == hipSuccess) e = hipMemcpy(t->jobs, jobs.data(), jobs.size() * sizeof(DwJob), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&t->map_pts, 96 * sizeof(short));
+    if (e == hipSuccess) e = hipMemcpy(t->map_pts, mp.data(), 96 * sizeof(short), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&t->map_feat, 64 * sizeof(short));
+    if (e == hipSuccess) e = hipMemcpy(t->map_feat, mf.data(), 64 * sizeof(short), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        zest_set_error("zest_mlp_train16: uploading tables: %s", hipGetErrorString(e));
+        delete t;
+        return nullptr;
+    }
+    g_tables[key] = t;
+    return t;
+}
+
+int cu_count() {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        cus = 256;
+    return cus;
+}
+
+}  // namespace
+
+extern "C" size_t zest_mlp_train16_stash_bytes(const zest_mlp_desc *desc, int M) {
+    if (!desc || M <= 0) return 0;
+    const Sizes s = sizes_of(M);
+    return s.tile_bytes + s.mask_bytes;
+}
+extern "C" size_t zest_mlp_train16_work_bytes(const zest_mlp_desc *desc, int M) {
+    if (!desc || M <= 0) return 0;
+    return sizes_of(M).grad_bytes + 2 * ZEST_P_COUNT * sizeof(float *);
+}
+extern "C" size_t zest_mlp_train16_packed_bytes(const zest_mlp_desc *desc) { return desc ? zest::bwd_stream_bytes(*desc) : 0; }
+
+extern "C" int zest_mlp_train16_pack(const zest_mlp_desc *desc, const float *const *params, void *packed, void *stream) {
+    ZEST_CHECK_ARG(desc && params && packed && ((uintptr_t)packed & 15) == 0, "zest_mlp_train16_pack: bad argument");
+    return zest::pack_bwd_stream(*desc, params, packed, (hipStream_t)stream);
+}
+
+extern "C" int zest_mlp_train16_fwd(const zest_mlp_desc *desc, const void *packed_fwd, const float *x, int M, void *stash,
+                                    float *out, void *stream) {
+    ZEST_CHECK_ARG(desc && packed_fwd && x && stash && out && M > 0, "zest_mlp_train16_fwd: bad argument");
+    ZEST_CHECK_ARG(((uintptr_t)stash & 15) == 0, "zest_mlp_train16_fwd: stash must be 16-byte aligned");
+    TrainTables *t = tables_for(*desc);
+    if (!t) return (int)hipErrorInvalidValue;
+    const Sizes s = sizes_of(M);
+    const void *tiles = (const char *)packed_fwd + t->fwd.bias_bytes;
+    return zest::mlp_engine_train_launch(t->fwd, tiles, x, M, out, stash, (char *)stash + s.tile_bytes, (hipStream_t)stream);
+}
+
+extern "C" int zest_mlp_train16_bwd(const zest_mlp_desc *desc, const void *packed_bwd, const float *const *params,
+                                    const float *x, int M, const void *stash, const float *out, const float *g_out,
+                                    void *work, float *g_x, float *const *g_params, int stages, void *stream) {
+    ZEST_CHECK_ARG(desc && packed_bwd && params && x && stash && out && g_out && work && g_x && g_params && M > 0,
+                   "zest_mlp_train16_bwd: bad argument");
+    ZEST_CHECK_ARG((((uintptr_t)work | (uintptr_t)stash | (uintptr_t)packed_bwd) & 15) == 0, "zest_mlp_train16_bwd: 16-byte alignment");
+    TrainTables *t = tables_for(*desc);
+    if (!t) return (int)hipErrorInvalidValue;
+    const Sizes s = sizes_of(M);
+    hipStream_t st = (hipStream_t)stream;
+    const zest_mlp_desc &d = *desc;
+    const bool mod = d.use_feat != 0;
+    const int F = mod ? d.in_ch_feat : 0, P = d.in_ch_pts, C_in = P + F + d.in_ch_views;
+    const int C_out = d.head == ZEST_HEAD_NONE ? 4 : (d.head == ZEST_HEAD_BLEND ? 5 : 12);
+    const uint4 *stash_tiles = (const uint4 *)stash;
+    const uint2 *masks = (const uint2 *)((const char *)stash + s.tile_bytes);
+    uint4 *grad = (uint4 *)work;
+    float **g_dev = (float **)((char *)work + s.grad_bytes);
+    const int cus = cu_count();
+    if (stages & 1) {
+        const int units = zest::bwd_stream_units_of(d);
+        const long long n_pass = (((long long)M + 31) / 32 + kWaves - 1) / kWaves;
+        const int blocks = (int)(n_pass < cus ? n_pass : cus);
+#define ZEST_DATA(NTP, MODF, NTF)                                                                              \
+    do {                                                                                                       \
+        ZEST_CHECK_ARG(units == bwd_stream_units(NTP, MODF ? NTF : 0), "zest_mlp_train16_bwd: stream of %d units, kernel expects %d", \
+                       units, bwd_stream_units(NTP, MODF ? NTF : 0));                                          \
+        hipLaunchKernelGGL((train16_data_kernel<NTP, MODF, NTF>), dim3(blocks), dim3(kWaves * 64), 0, st,      \
+                           (const uint4 *)packed_bwd, x, out, g_out, M, P, F, C_in, C_out, d.head, masks, t->map_pts, grad, g_x); \
+    } while (0)
+        const int key = t->fwd.nt_pts * 10 + (mod ? t->fwd.nt_feat : 0);
+        switch (key) {
+            case 40: ZEST_DATA(4, false, 0); break;
+            case 42: ZEST_DATA(4, true, 2); break;
+            case 44: ZEST_DATA(4, true, 4); break;
+            case 60: ZEST_DATA(6, false, 0); break;
+            case 62: ZEST_DATA(6, true, 2); break;
+            case 64: ZEST_DATA(6, true, 4); break;
+            default:
+                zest_set_error("zest_mlp_train16_bwd: no data kernel for %d point units / %d feature units", t->fwd.nt_pts,
+                               mod ? t->fwd.nt_feat : 0);
+                return (int)hipErrorInvalidValue;
+        }
+#undef ZEST_DATA
+    }
+    if ((stages & 2) && mod) {
+        const long long n_blocks = ((long long)M + 31) / 32;
+        const float *wm = params[2 * ZEST_P_PTS_BIAS], *bm = params[2 * ZEST_P_PTS_BIAS + 1];
+        if (t->fwd.nt_feat == 2)
+            hipLaunchKernelGGL((train16_mod_kernel<2>), dim3(zest_div_up(n_blocks, 4)), dim3(256), 0, st, x, M, P, F, C_in, wm, bm,
+                               stash_tiles, grad, t->map_feat, g_x);
+        else
+            hipLaunchKernelGGL((train16_mod_kernel<4>), dim3(zest_div_up(n_blocks, 4)), dim3(256), 0, st, x, M, P, F, C_in, wm, bm,
+                               stash_tiles, grad, t->map_feat, g_x);
+    }
+    if (stages & 4) {
+        hipError_t e = hipMemcpyAsync(g_dev, g_params, 2 * ZEST_P_COUNT * sizeof(float *), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) {
+            zest_set_error("zest_mlp_train16_bwd: uploading the gradient pointers: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        int wg_per_job = (2 * cus) / t->n_jobs;
+        if (wg_per_job < 1) wg_per_job = 1;
+        const long long n_blocks = ((long long)M + 31) / 32;
+        if (wg_per_job > n_blocks) wg_per_job = (int)n_blocks;
+        hipLaunchKernelGGL(train16_dw_kernel, dim3(t->n_jobs * wg_per_job), dim3(kWaves * 64), 0, st, t->jobs, wg_per_job,
+                           stash_tiles, (const uint4 *)grad, x, M, P, F, C_in, P == 63 ? 3 : 4, (float *const *)g_dev);
+    }
+    ZEST_RETURN_LAUNCH("zest_mlp_train16_bwd");
+}

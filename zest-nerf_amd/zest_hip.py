@@ -82,6 +82,13 @@ _SIGS = {
     "zest_mlp_train_fwd": (_i, [C.POINTER(MlpDesc), C.POINTER(_vp), _vp, _i, _vp, _vp, _vp, _vp]),
     "zest_mlp_train_bwd": (_i, [C.POINTER(MlpDesc), C.POINTER(_vp), _vp, _i, _vp, _vp, _vp, _vp, _vp,
                                 C.POINTER(_vp), _vp]),
+    "zest_mlp_train16_stash_bytes": (_sz, [C.POINTER(MlpDesc), _i]),
+    "zest_mlp_train16_work_bytes": (_sz, [C.POINTER(MlpDesc), _i]),
+    "zest_mlp_train16_packed_bytes": (_sz, [C.POINTER(MlpDesc)]),
+    "zest_mlp_train16_pack": (_i, [C.POINTER(MlpDesc), C.POINTER(_vp), _vp, _vp]),
+    "zest_mlp_train16_fwd": (_i, [C.POINTER(MlpDesc), _vp, _vp, _i, _vp, _vp, _vp]),
+    "zest_mlp_train16_bwd": (_i, [C.POINTER(MlpDesc), _vp, C.POINTER(_vp), _vp, _i, _vp, _vp, _vp, _vp, _vp,
+                                  C.POINTER(_vp), _i, _vp]),
     "zest_mlp_packed_bytes": (_sz, [C.POINTER(MlpDesc), _i]),
     "zest_mlp_pack": (_i, [C.POINTER(MlpDesc), _i, C.POINTER(_vp), _vp, _vp]),
     "zest_mlp_fwd": (_i, [C.POINTER(MlpDesc), _i, _vp, _vp, _i, _vp, _vp]),
@@ -493,6 +500,44 @@ def mlp_train_bwd(desc, params, x, saved, out, g_out, want_gx=True):
     _check(L.zest_mlp_train_bwd(C.byref(desc), _ptr_table(keep), _ptr(x), M, _ptr(saved), _ptr(out), _ptr(g_out),
                                 _ptr(work), _ptr(g_x), _ptr_table(grads), _stream(x)), "zest_mlp_train_bwd")
     return g_x, grads
+
+
+# ------------------------------------------------ bf16 training path on the MFMA engine
+def mlp_train16_pack_bwd(desc, params):
+    """Transposed weight stream of the backward data kernel (params as for mlp_pack)."""
+    dev = next(p for p in params if p is not None).device
+    keep = [(_dev(p, "param") if p is not None else None) for p in params]
+    packed = torch.empty(int(lib().zest_mlp_train16_packed_bytes(C.byref(desc))), device=dev, dtype=torch.uint8)
+    _check(lib().zest_mlp_train16_pack(C.byref(desc), _ptr_table(keep), _ptr(packed),
+                                       torch.cuda.current_stream(dev).cuda_stream), "zest_mlp_train16_pack")
+    return packed
+
+
+def mlp_train16_fwd(desc, packed_fwd, x):
+    """x [M, C_in] -> out [M, C_out], stash (opaque: layer outputs as bf16 operand tiles + ReLU masks)."""
+    x = _dev(x, "x")
+    M = x.numel() // x.shape[-1]
+    stash = torch.empty(int(lib().zest_mlp_train16_stash_bytes(C.byref(desc), M)), device=x.device, dtype=torch.uint8)
+    out = torch.empty(*x.shape[:-1], desc.out_ch, device=x.device, dtype=torch.float32)
+    _check(lib().zest_mlp_train16_fwd(C.byref(desc), _ptr(packed_fwd), _ptr(x), M, _ptr(stash), _ptr(out), _stream(x)),
+           "zest_mlp_train16_fwd")
+    return out, stash
+
+
+def mlp_train16_bwd(desc, packed_bwd, params, x, stash, out, g_out, stages=7, work=None):
+    """-> g_x [M, C_in] (direction columns zero), list of 2*P_COUNT fp32 parameter gradients (None where absent)."""
+    x, g_out, out = _dev(x, "x"), _dev(g_out, "g_out"), _dev(out, "out")
+    M = x.numel() // x.shape[-1]
+    need = int(lib().zest_mlp_train16_work_bytes(C.byref(desc), M))
+    if work is None or work.numel() < need:
+        work = torch.empty(need, device=x.device, dtype=torch.uint8)
+    keep = [(_dev(p, "param") if p is not None else None) for p in params]
+    grads = [(torch.zeros_like(p) if p is not None else None) for p in keep]
+    g_x = torch.zeros_like(x)
+    _check(lib().zest_mlp_train16_bwd(C.byref(desc), _ptr(packed_bwd), _ptr_table(keep), _ptr(x), M, _ptr(stash), _ptr(out),
+                                      _ptr(g_out), _ptr(work), _ptr(g_x), _ptr_table(grads), int(stages), _stream(x)),
+           "zest_mlp_train16_bwd")
+    return g_x, grads, work
 
 
 # ----------------------------------------------------------------------------------- MLP

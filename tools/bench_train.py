@@ -28,10 +28,12 @@ def main():
     ap.add_argument("--frames", type=int, default=3, choices=[3, 5])
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--cpu-rays", type=int, default=64)
+    ap.add_argument("--precision", type=int, default=16, choices=[16, 32],
+                    help="16: bf16 MFMA training kernels (MlpFn16); 32: fp32 parity path (rocBLAS sgemm)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     d = bench.build_workload("nsff_zest_val_1024x128", 5, dev, a.rays)
-    d.args.precision, d.args.zest_maps_only = 32, False
+    d.args.precision, d.args.zest_maps_only = a.precision, False
     vol_s, vol_d = d.vol_s.clone().requires_grad_(True), d.vol_d.clone().requires_grad_(True)
     params = list(d.net_s.parameters()) + list(d.net_d.parameters())
 
@@ -53,14 +55,18 @@ def main():
     for _ in range(3):
         step()
     torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
-    out = {"op": "train step (rendering fwd + bwd, %d-frame ZeST, fp32)" % a.frames, "rays": d.R, "samples": d.S,
+    out = {"op": "train step (rendering fwd + bwd, %d-frame ZeST, %s MLP)" % (a.frames, "bf16 MFMA" if a.precision == 16 else "fp32 rocBLAS"), "rays": d.R, "samples": d.S,
            "ms_per_step": dt * 1e3, "rays_per_s": d.R / dt,
            "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}
+    if a.cpu_rays <= 0:
+        print(json.dumps(out))
+        return
     # CPU: oracle + autograd on a subset of the same rays
     from oracle import zest_oracle as zo
     sc, Rc = d.sc, a.cpu_rays

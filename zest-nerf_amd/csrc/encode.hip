@@ -133,64 +133,64 @@ __global__ void encode_kernel(const float *__restrict__ ndc, const float *__rest
 // lookup's dependence on them - needed for the scene-flow displaced points, renderer.py:461,488)
 // and the encoding volume itself (scatter-add; MVSNet trains through it).  World points, source
 // images, cameras and ray directions are data and receive no gradient.
+// Eight lanes per sample (lane & 7 = volume channel): a corner's scatter-add is then 8 adjacent floats = one
+// 32-byte segment per sample and 8 segments per wave instruction, instead of 64 single floats in 64 different
+// rows (the shape at which memory-side float atomics run at 1/17 of their rate: the first version of this
+// kernel spent 0.45 ms per 1024 x 128 batch on them).  The octet's lanes 0-2 also take one coordinate each of
+// the positional-encoding part; the per-corner dot products are reduced over the octet with shuffles.
 __global__ void encode_bwd_kernel(const float *__restrict__ g_x, const float *__restrict__ ndc, int R, int S,
                                   int has_time, float t, const float4 *__restrict__ vol, int D, int Hv, int Wv,
                                   int V, float *__restrict__ g_ndc, float *__restrict__ g_vol) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= R * S) return;
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long m_raw = tid >> 3;
+    const int ch = (int)(tid & 7);
+    const bool live = m_raw < (long long)R * S;
+    const long long m = live ? m_raw : 0;                     // idle octets compute on sample 0 and store nothing
     const int C = 3 + has_time;
     const int P = C * 21, F = vol ? 8 + 4 * V : 0;
     const float *row = g_x + (size_t)m * (P + F + 27);
     const float p[3] = {ndc[3 * m], ndc[3 * m + 1], ndc[3 * m + 2]};
-    float g[3];
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        float acc = row[c], f = 1.0f;
+    float gpe = 0.0f;                                          // lanes 0-2: d / d coordinate ch through the encoding
+    if (ch < 3) {
+        float acc = row[ch], f = 1.0f;
         for (int k = 0; k < 10; k++) {
             float sn, cs;
-            zest_sincos(p[c] * f, &sn, &cs);
-            acc += f * (cs * row[C * (1 + 2 * k) + c] - sn * row[C * (2 + 2 * k) + c]);
+            zest_sincos(p[ch] * f, &sn, &cs);
+            acc += f * (cs * row[C * (1 + 2 * k) + ch] - sn * row[C * (2 + 2 * k) + ch]);
             f *= 2.0f;
         }
-        g[c] = acc;
+        gpe = acc;
     }
+    float dxs = 0.f, dys = 0.f, dzs = 0.f;
     if (vol) {
-        float gf[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) gf[i] = row[P + i];
-        float fx = zest_unnorm(p[0], Wv), fy = zest_unnorm(p[1], Hv), fz = zest_unnorm(p[2], D);
+        const float gf = row[P + ch];
+        const float fx = zest_unnorm(p[0], Wv), fy = zest_unnorm(p[1], Hv), fz = zest_unnorm(p[2], D);
         const bool inside = fx > -2.0f && fx < (float)Wv + 1.0f && fy > -2.0f && fy < (float)Hv + 1.0f &&
                             fz > -2.0f && fz < (float)D + 1.0f;
-        if (inside) {
-            const float x0f = floorf(fx), y0f = floorf(fy), z0f = floorf(fz);
-            const float tx = fx - x0f, ty = fy - y0f, tz = fz - z0f;
-            const int x0 = (int)x0f, y0 = (int)y0f, z0 = (int)z0f;
-            float dxs = 0.f, dys = 0.f, dzs = 0.f;
+        const float x0f = floorf(fx), y0f = floorf(fy), z0f = floorf(fz);
+        const float tx = fx - x0f, ty = fy - y0f, tz = fz - z0f;
+        const int x0 = inside ? (int)x0f : -8, y0 = inside ? (int)y0f : -8, z0 = inside ? (int)z0f : -8;
+        const float *volf = reinterpret_cast<const float *>(vol);
 #pragma unroll
-            for (int c = 0; c < 8; c++) {
-                const int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
-                const int xi = x0 + dx, yi = y0 + dy, zi = z0 + dz;
-                if ((unsigned)xi < (unsigned)Wv && (unsigned)yi < (unsigned)Hv && (unsigned)zi < (unsigned)D) {
-                    const size_t vox = ((size_t)zi * Hv + yi) * Wv + xi;
-                    const float wx = dx ? tx : 1.0f - tx, wy = dy ? ty : 1.0f - ty, wz = dz ? tz : 1.0f - tz;
-                    const float4 a = vol[2 * vox], b = vol[2 * vox + 1];
-                    const float dot = a.x * gf[0] + a.y * gf[1] + a.z * gf[2] + a.w * gf[3] + b.x * gf[4] +
-                                      b.y * gf[5] + b.z * gf[6] + b.w * gf[7];
-                    dxs += (dx ? 1.0f : -1.0f) * wy * wz * dot;
-                    dys += (dy ? 1.0f : -1.0f) * wx * wz * dot;
-                    dzs += (dz ? 1.0f : -1.0f) * wx * wy * dot;
-                    if (g_vol) {
-                        const float w = wx * wy * wz;
-                        float *gv = g_vol + 8 * vox;
-#pragma unroll
-                        for (int i = 0; i < 8; i++) atomicAdd(gv + i, w * gf[i]);
-                    }
-                }
-            }
-            g[0] += dxs * (float)(Wv - 1), g[1] += dys * (float)(Hv - 1), g[2] += dzs * (float)(D - 1);
+        for (int c = 0; c < 8; c++) {
+            const int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
+            const int xi = x0 + dx, yi = y0 + dy, zi = z0 + dz;
+            const bool ok = (unsigned)xi < (unsigned)Wv && (unsigned)yi < (unsigned)Hv && (unsigned)zi < (unsigned)D;
+            const size_t vox = ok ? ((size_t)zi * Hv + yi) * Wv + xi : 0;
+            const float wx = dx ? tx : 1.0f - tx, wy = dy ? ty : 1.0f - ty, wz = dz ? tz : 1.0f - tz;
+            float dot = ok ? volf[8 * vox + ch] * gf : 0.0f;                    // octet-uniform `ok`
+            dot += __shfl_xor(dot, 1, 64), dot += __shfl_xor(dot, 2, 64), dot += __shfl_xor(dot, 4, 64);
+            dxs += (dx ? 1.0f : -1.0f) * wy * wz * dot;
+            dys += (dy ? 1.0f : -1.0f) * wx * wz * dot;
+            dzs += (dz ? 1.0f : -1.0f) * wx * wy * dot;
+            if (g_vol && ok && live) atomicAdd(g_vol + 8 * vox + ch, wx * wy * wz * gf);
         }
     }
-    g_ndc[3 * m] = g[0], g_ndc[3 * m + 1] = g[1], g_ndc[3 * m + 2] = g[2];
+    if (live && ch < 3) {
+        const float scale = ch == 0 ? (float)(Wv - 1) : (ch == 1 ? (float)(Hv - 1) : (float)(D - 1));
+        const float dv = ch == 0 ? dxs : (ch == 1 ? dys : dzs);
+        g_ndc[3 * m + ch] = gpe + (vol ? dv * scale : 0.0f);
+    }
 }
 
 // channels-last gradient volume [D,H,W,8] -> the reference's layout [8,D,H,W]
@@ -215,7 +215,7 @@ extern "C" int zest_encode_bwd(const float *g_x, const float *ndc, int R, int S,
                    "zest_encode_bwd: bad volume");
     ZEST_CHECK_ARG(!g_vol_cl || vol_cl, "zest_encode_bwd: g_vol_cl needs vol_cl");
     if (R == 0) return 0;
-    hipLaunchKernelGGL(encode_bwd_kernel, dim3(zest_div_up((long long)R * S, kThreads)), dim3(kThreads), 0,
+    hipLaunchKernelGGL(encode_bwd_kernel, dim3(zest_div_up((long long)R * S * 8, kThreads)), dim3(kThreads), 0,
                        (hipStream_t)stream, g_x, ndc, R, S, has_time ? 1 : 0, t, (const float4 *)vol_cl, D, Hv,
                        Wv, V, g_ndc, g_vol_cl);
     ZEST_RETURN_LAUNCH("zest_encode_bwd");

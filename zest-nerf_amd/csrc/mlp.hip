@@ -247,9 +247,9 @@ size_t bwd_stream_bytes(const zest_mlp_desc &d) {
     DevPlan *dp = get_plan(d, ZEST_PREC_BF16, kOrderBwd, false);
     return dp ? dp->plan.bytes : 0;
 }
-int bwd_stream_units_of(const zest_mlp_desc &d) {
+int bwd_stream_units_of(const zest_mlp_desc &d) {          // the ring-streamed part (the modulation^T tail follows it)
     DevPlan *dp = get_plan(d, ZEST_PREC_BF16, kOrderBwd, false);
-    return dp ? dp->plan.n_tiles : -1;
+    return dp ? dp->plan.tail_unit0 : -1;
 }
 int pack_bwd_stream(const zest_mlp_desc &d, const float *const *params, void *packed, hipStream_t stream) {
     DevPlan *dp = get_plan(d, ZEST_PREC_BF16, kOrderBwd, true);

@@ -82,6 +82,7 @@ struct MlpPlan {
     int spt;                       // slots per tile
     int ns_pts, ns_feat, ns_views; // padded slot counts of the encoder operands
     int nt_pts, nt_feat, nt_views, nt_h, nt_h128;
+    int tail_unit0;                // backward stream: first unit of the modulation^T tail (after the padded ring part)
     int headers;                   // 1: ORDER_ACC stream with inline header units
     int parts;                     // stream units per weight tile: 1, or 2 (hi, lo) for ZEST_PREC_F16X3
     int n_tiles, n_bias_blocks;    // n_tiles includes headers and tail padding
@@ -108,8 +109,11 @@ inline bool prec_is_engine(int precision) {     // the register engine's operand
 // (rgb, view layer, feature_linear + heads, trunk layers 7 .. 0), same unit format as the forward
 // ORDER_ACC stream: per row block of 32 INPUT features a header (bias block zero, modulation bias
 // block of the layer whose ReLU mask / modulation the epilogue applies), its modulation tiles, then
-// per k-tile of OUTPUT-feature positions the row tiles 0, 1.  Built into an MlpPlan so the forward
-// packer packs it (tile_src / hdr_src / n_tiles / bytes are the fields used).
+// per k-tile of OUTPUT-feature positions the row tiles 0, 1.  Behind the ring-aligned part follows a
+// tail the data kernel does not stream, read directly by the finishing kernel: pts_bias^T (rows = feature
+// positions, k = the 256 modulation features; 17 units per row block), then per row block of m its
+// header + modulation tiles (1 + nt_feat units) as in the forward stream.  Built into an MlpPlan so the forward packer packs
+// it (tile_src / hdr_src / n_tiles / tail_unit0 / bytes are the fields used).
 bool build_bwd_plan(const zest_mlp_desc &d, MlpPlan *out, const char **err);
 // row blocks / k-tiles of the backward ops, shared by the plan builder and the kernel's unrolled walk
 constexpr int bwd_stream_units_raw(int nt_pts, int nt_feat) {

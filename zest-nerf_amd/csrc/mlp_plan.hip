@@ -253,6 +253,7 @@ struct BwdCtx {
 
 // (param slot, row) of output feature `o` of a forward op; op ids as in build_plan (8 = head tile)
 inline RowSrc out_row_of(const zest_mlp_desc &d, int op, int o) {
+    if (op == 100) return {ZEST_P_PTS_BIAS, o};                  // the modulation Linear
     if (op < 8) return {ZEST_P_PTS0 + op, o};
     if (op == 9) return {ZEST_P_FEATURE, o};
     if (op == 10) return {o < kW / 2 ? ZEST_P_VIEWS : -1, o};
@@ -335,8 +336,18 @@ bool build_bwd_plan(const zest_mlp_desc &d, MlpPlan *P, const char **err) {
         emit_bwd_row_block(c, [&](int i) { return (int)p.map_pts[32 * jb + i]; }, -1, sg, 1);
     }
     if (c.t != bwd_stream_units_raw(p.nt_pts, mod ? p.nt_feat : 0)) return *err = "backward stream: unit count mismatch", false;
-    const int total = round_up(c.t, kStreamAlign);
+    int total = round_up(c.t, kStreamAlign);
     c.grow(total - c.t);
+    c.t = total;
+    p.tail_unit0 = total;
+    if (mod) {          // tail: pts_bias^T (rows = feature positions), then the forward's modulation units per row block
+        for (int jb = 0; jb < p.nt_feat / 2; jb++) {
+            const int sg[1][2] = {{100, 8}};
+            emit_bwd_row_block(c, [&](int i) { return (int)p.map_feat[32 * jb + i]; }, -1, sg, 1);
+        }
+        for (int jb = 0; jb < 8; jb++) emit_bwd_row_block(c, [](int) { return -1; }, jb, nullptr, 0);
+    }
+    total = c.t;
     p.headers = 1, p.parts = 1, p.n_tiles = total, p.n_bias_blocks = 0, p.bias_bytes = 0;
     p.bytes = (size_t)total * 1024;
     p.tile_src.swap(c.tile_src), p.hdr_src.swap(c.hdr_src);
@@ -361,7 +372,7 @@ int build_dw_jobs(const zest_mlp_desc &d, std::vector<DwJob> *jobs, const char *
             j.out_slot[pos] = -1, j.out_row[pos] = 0, j.in_col[pos] = -1;
             if (pos < 32 * n_out) {
                 const int o = h_feature(ORDER_ACC, 8, pos, 0);
-                const RowSrc rs = op == 100 ? RowSrc{ZEST_P_PTS_BIAS, o} : out_row_of(d, op, o);
+                const RowSrc rs = out_row_of(d, op, o);
                 j.out_slot[pos] = (int16_t)rs.param, j.out_row[pos] = (int16_t)rs.row;
             }
             if (pos < 32 * n_in)

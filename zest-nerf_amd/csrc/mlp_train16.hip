@@ -39,9 +39,11 @@ using namespace zest;
 constexpr int EP = ZEST_PREC_BF16;
 constexpr int kWaves = 8;
 
+constexpr int kPtsSideFloat4 = 2 * 3 * 2 * 2 * 64;      // point-gradient side buffer per block: [layer 5 | 0][row block < 3][CB][row tile][lane]
+
 struct Sizes {
     long long blocks;
-    size_t tile_bytes, mask_bytes, grad_bytes;
+    size_t tile_bytes, mask_bytes, grad_bytes, side_bytes;
 };
 Sizes sizes_of(int M) {
     Sizes s;
@@ -49,6 +51,7 @@ Sizes sizes_of(int M) {
     s.tile_bytes = (size_t)s.blocks * kStashTiles * 2 * 1024;
     s.mask_bytes = (size_t)s.blocks * kStashMasks * 2 * 64 * 8;
     s.grad_bytes = (size_t)s.blocks * kGradTiles * 2 * 1024;
+    s.side_bytes = (size_t)s.blocks * kPtsSideFloat4 * 16;
     return s;
 }
 
@@ -148,21 +151,19 @@ struct MaskEpi {
     __device__ __forceinline__ void rows(int, int, const float (&)[8]) const {}
 };
 
-// point-encoding rows: row 16 rt + 4 g + r of row block jb is operand position 32 jb + that; its column in x
-// comes from the position map (kept in LDS)
+// point-encoding rows (layers 5 and 0): the raw sums of a row block go to a side buffer exactly as the lanes
+// hold them (two float4 per lane: rows 4g..4g+3 of row tiles 0 / 1; 1 KiB per wave store, coalesced); the
+// finishing kernel adds the two layers' contributions and scatters them into the columns of g_x.  (Float
+// atomics straight into g_x - every lane another row - ran at 1/17 of the atomic rate and dominated the kernel.)
 template <int CB>
 struct PtsEpi {
-    float *gx[CB];          // g_x row of this lane's sample in each column block (nullptr: past M)
-    const short *map;       // LDS: position -> column of the point encoding, -1 none
-    int grp;
+    float4 *side;           // this block's side buffer
+    int which, lane;        // 0: layer 5, 1: layer 0
     __device__ __forceinline__ void tile(int, int, float (&)[8], const float (&)[8]) const {}
     __device__ __forceinline__ void rows(int jb, int cb, const float (&v)[8]) const {
-        if (!gx[cb]) return;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int pos = 32 * jb + 16 * (i >> 2) + 4 * grp + (i & 3), col = map[pos];
-            if (col >= 0) atomicAdd(gx[cb] + col, v[i]);
-        }
+        float4 *o = side + ((((which * 3 + jb) * CB + cb) * 2) * 64 + lane);
+        o[0] = make_float4(v[0], v[1], v[2], v[3]);
+        o[64] = make_float4(v[4], v[5], v[6], v[7]);
     }
 };
 
@@ -170,15 +171,11 @@ template <int NT_PTS, bool MOD, int NT_FEAT>
 __global__ __launch_bounds__(kWaves * 64, kWaves / 4) void train16_data_kernel(
     const uint4 *__restrict__ stream, const float *__restrict__ x, const float *__restrict__ out,
     const float *__restrict__ g_out, int M, int P, int F, int C_in, int C_out, int head,
-    const uint2 *__restrict__ masks, const short *__restrict__ map_pts_g, uint4 *__restrict__ grad,
-    float *__restrict__ g_x) {
+    const uint2 *__restrict__ masks, uint4 *__restrict__ grad, float4 *__restrict__ pts_side) {
     constexpr int CB = 2, KP = NT_PTS / 2, KF = NT_FEAT / 2;
     constexpr int UNITS = bwd_stream_units(NT_PTS, MOD ? NT_FEAT : 0);
     using Ring = RingTiles<kWaves, UNITS, 0>;
-    __shared__ __attribute__((aligned(16))) char lds[kRingUnits * 1024 + 2 * kSlots * 4 + 96 * 2];
-    short *map_pts = reinterpret_cast<short *>(lds + kRingUnits * 1024 + 2 * kSlots * 4);
-    if (threadIdx.x < 32 * KP) map_pts[threadIdx.x] = map_pts_g[threadIdx.x];
-    __syncthreads();
+    __shared__ __attribute__((aligned(16))) char lds[kRingUnits * 1024 + 2 * kSlots * 4];
     const int lane = threadIdx.x & 63, col = lane & 15, grp = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const Ring tiles{lds, (gptr_u4)stream, (gptr_u4)stream, lane, grp, wave,
@@ -195,14 +192,12 @@ __global__ __launch_bounds__(kWaves * 64, kWaves / 4) void train16_data_kernel(
         OpArr<1> d_rgb[CB], d_head[CB];
         OpArr<KF> feat[CB];
         OpArr<0> none[CB];
-        float *gx_row[CB];
         // ---- gradients of the raw network outputs from g_out (activation derivatives through `out`)
 #pragma unroll
         for (int cb = 0; cb < CB; cb++) {
             const long long m = m_base + 16 * cb + col;
             const bool valid = m < M;
             const float *go = g_out + (size_t)(valid ? m : 0) * C_out, *o = out + (size_t)(valid ? m : 0) * C_out;
-            gx_row[cb] = valid ? g_x + (size_t)m * C_in : nullptr;
             float r[8] = {0, 0, 0, 0, 0, 0, 0, 0}, h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             if (valid) {
                 if (grp == 0) {
@@ -248,120 +243,137 @@ __global__ __launch_bounds__(kWaves * 64, kWaves / 4) void train16_data_kernel(
         // 3. feature_linear^T | heads^T -> d h7, masked and modulated as layer 7 -> d pre_7
         bwd_layer<CB, 8, 8, 1, MOD, KF, 0>(tiles, unit, gb, d_head, feat, ga, mask_epi(7, 56));
         // 4. trunk layers 7 .. 1 (layer 5: the point rows first)
-        PtsEpi<CB> pe;
-        pe.map = map_pts, pe.grp = grp;
-#pragma unroll
-        for (int cb = 0; cb < CB; cb++) pe.gx[cb] = gx_row[cb];
+        PtsEpi<CB> pe5{pts_side + (size_t)block * kPtsSideFloat4, 0, lane}, pe0{pts_side + (size_t)block * kPtsSideFloat4, 1, lane};
         bwd_layer<CB, 8, 8, 0, MOD, KF, 0>(tiles, unit, ga, none, feat, gb, mask_epi(6, 48));     // layer 7 -> d pre_6
         bwd_layer<CB, 8, 8, 0, MOD, KF, 0>(tiles, unit, gb, none, feat, ga, mask_epi(5, 40));     // layer 6 -> d pre_5
-        bwd_layer<CB, KP, 8, 0, false, KF, 2>(tiles, unit, ga, none, feat, gb, pe);                // layer 5: points
+        bwd_layer<CB, KP, 8, 0, false, KF, 2>(tiles, unit, ga, none, feat, gb, pe5);               // layer 5: points
         bwd_layer<CB, 8, 8, 0, MOD, KF, 0>(tiles, unit, ga, none, feat, gb, mask_epi(4, 32));     // layer 5 -> d pre_4
         bwd_layer<CB, 8, 8, 0, MOD, KF, 0>(tiles, unit, gb, none, feat, ga, mask_epi(3, 24));     // layer 4 -> d pre_3
         bwd_layer<CB, 8, 8, 0, MOD, KF, 0>(tiles, unit, ga, none, feat, gb, mask_epi(2, 16));     // layer 3 -> d pre_2
         bwd_layer<CB, 8, 8, 0, MOD, KF, 0>(tiles, unit, gb, none, feat, ga, mask_epi(1, 8));      // layer 2 -> d pre_1
         bwd_layer<CB, 8, 8, 0, MOD, KF, 0>(tiles, unit, ga, none, feat, gb, mask_epi(0, 0));      // layer 1 -> d pre_0
-        bwd_layer<CB, KP, 8, 0, false, KF, 2>(tiles, unit, gb, none, feat, ga, pe);                // layer 0: points
+        bwd_layer<CB, KP, 8, 0, false, KF, 2>(tiles, unit, gb, none, feat, ga, pe0);               // layer 0: points
         tiles.finish(unit, UNITS);
         tiles.next_pass();
     }
     tiles.drain();
 }
 
-// ------------------------------------------------------------------------------ modulation kernel
-// d m [sample][256] = sum over the 8 trunk layers of d pre_l * h_l / m^2 (d pre_l = d h_l mask m, h_l = pre_l m:
-// the product is d h_l mask pre_l), written as gradient-stash tiles 78 .. 85; d features = Wm^T d m into g_x.
-// One wave per block of 32 samples, everything from global memory / L2 (no ring): m is recomputed with
-// the forward's modulation tiles (fwd stream), Wm^T tiles come from the backward stream's row blocks.
-template <int NT_FEAT>
-__global__ __launch_bounds__(256) void train16_mod_kernel(const float *__restrict__ x, int M, int P, int F, int C_in,
-                                                           const float *__restrict__ wm, const float *__restrict__ bm,
-                                                           const uint4 *__restrict__ stash, uint4 *__restrict__ grad,
-                                                           const short *__restrict__ map_feat, float *__restrict__ g_x) {
-    constexpr int CB = 2, KF = NT_FEAT / 2;
+// ------------------------------------------------------------------------------ finishing kernel
+// Per block of 32 samples, one wave, everything straight from global memory / L2 (no ring):
+//   * point-encoding gradient: the two side-buffer contributions (layers 5 and 0) are added and scattered
+//     into the point columns of g_x through the position map;
+//   * modulation (nets with features): m is recomputed with the forward stream's modulation tiles (MFMA),
+//     d m = sum over the 8 trunk layers of d pre_l * h_l / m^2 from the two stashes (d pre_l = d h_l mask m and
+//     h_l = pre_l m, so the product is d h_l mask pre_l) becomes gradient tiles 78 .. 85 for the weight kernel,
+//     and d features = Wm^T d m (MFMA with the backward stream's tail) goes to the feature columns of g_x.
+template <int NT_PTS, int NT_FEAT>
+__global__ __launch_bounds__(256) void train16_finish_kernel(
+    const float *__restrict__ x, int M, int P, int F, int C_in, const uint4 *__restrict__ bwd_tail,
+    const uint4 *__restrict__ stash, uint4 *__restrict__ grad,
+    const float4 *__restrict__ pts_side, const short *__restrict__ map_pts, const short *__restrict__ map_feat,
+    float *__restrict__ g_x) {
+    constexpr int CB = 2, KP = NT_PTS / 2, KF = NT_FEAT / 2;
     const int lane = threadIdx.x & 63, col = lane & 15, grp = lane >> 4;
     const long long block = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (block * 32 >= M) return;
-    const uint4 *sblk = stash + (size_t)block * kStashTiles * CB * 64;
-    uint4 *gblk = grad + (size_t)block * kGradTiles * CB * 64;
-    float fvals[CB][KF * 8];       // this lane's feature values (operand positions), fp32
-    bool valid[CB];
+    if (block * 32 >= M) return;                                   // wave-uniform
+    float *gx_row[CB];
 #pragma unroll
     for (int cb = 0; cb < CB; cb++) {
         const long long m = block * 32 + 16 * cb + col;
-        valid[cb] = m < M;
-        const float *xf = x + (size_t)(valid[cb] ? m : 0) * C_in + P;
-#pragma unroll
-        for (int t = 0; t < KF; t++)
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const int c = map_feat[32 * t + 8 * grp + e];
-                fvals[cb][8 * t + e] = (valid[cb] && c >= 0) ? xf[c] : 0.0f;
-            }
+        gx_row[cb] = m < M ? g_x + (size_t)m * C_in : nullptr;
     }
-    // Each lane needs m and accumulates d m for the 8 features (4g..4g+3, 16+4g..) of every block of 32: the
-    // features of operand position 8g+e.  Every lane (col, g) holds the feature values of positions 8g..8g+7 of
-    // its sample only, so m = Wm f needs the other groups' values: gather them with lane shuffles.
-#pragma unroll 1
-    for (int cb = 0; cb < CB; cb++) {
-        float fall[KF * 32];       // all feature positions of this lane's sample
+    // ---- point columns
+    const float4 *side = pts_side + (size_t)block * kPtsSideFloat4;
 #pragma unroll
-        for (int t = 0; t < KF; t++)
+    for (int jb = 0; jb < KP; jb++)
 #pragma unroll
-            for (int gsrc = 0; gsrc < 4; gsrc++)
+        for (int cb = 0; cb < CB; cb++)
 #pragma unroll
-                for (int e = 0; e < 8; e++)
-                    fall[32 * t + 8 * gsrc + e] = __shfl(fvals[cb][8 * t + e], col + 16 * gsrc, 64);
-        float dall[KF * 32];       // d feature positions: every group adds its 64 features' share
+            for (int rt = 0; rt < 2; rt++) {
+                const float4 a = side[(((0 * 3 + jb) * CB + cb) * 2 + rt) * 64 + lane];
+                const float4 b = side[(((1 * 3 + jb) * CB + cb) * 2 + rt) * 64 + lane];
+                const float v[4] = {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
+                if (!gx_row[cb]) continue;
 #pragma unroll
-        for (int i = 0; i < KF * 32; i++) dall[i] = 0.0f;
-#pragma unroll 1
+                for (int r = 0; r < 4; r++) {
+                    const int c = map_pts[32 * jb + 16 * rt + 4 * grp + r];
+                    if (c >= 0) gx_row[cb][c] = v[r];
+                }
+            }
+    if constexpr (KF > 0) {
+        const uint4 *sblk = stash + (size_t)block * kStashTiles * CB * 64;
+        uint4 *gblk = grad + (size_t)block * kGradTiles * CB * 64;
+        OpArr<KF> feat[CB];
+#pragma unroll
+        for (int cb = 0; cb < CB; cb++) {
+            const long long m = block * 32 + 16 * cb + col;
+            const bool valid = m < M;
+            load_feat_operand<EP, KF>(x + (size_t)(valid ? m : 0) * C_in + P, F, valid, grp, feat[cb]);
+        }
+        OpArr<8> dm[CB];
+#pragma unroll
         for (int jb = 0; jb < 8; jb++) {
-            float mval[8], dm[8];
+            // m of the row block: header (modulation bias block at byte 128) + NT_FEAT modulation tiles (tail, 2nd part)
+            const uint4 *u = bwd_tail + (size_t)(KF * 17 + jb * (1 + NT_FEAT)) * 64;
+            f32x4 macc[2][CB];
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const int f = 32 * jb + (e < 4 ? 4 * grp + e : 16 + 4 * grp + (e - 4));
-                float a = bm[f];
-                const float *wr = wm + (size_t)f * F;
-                for (int t = 0; t < KF; t++)
-                    for (int q = 0; q < 32; q++) {
-                        const int c = map_feat[32 * t + q];
-                        if (c >= 0) a = fmaf(wr[c], fall[32 * t + q], a);
-                    }
-                mval[e] = a, dm[e] = 0.0f;
+            for (int rt = 0; rt < 2; rt++) {
+                const float4 b4 = reinterpret_cast<const float4 *>(u)[8 + 4 * rt + grp];     // floats 32 + 16 rt + 4 g ..
+#pragma unroll
+                for (int cb = 0; cb < CB; cb++) macc[rt][cb] = f32x4{b4.x, b4.y, b4.z, b4.w};
             }
-            for (int l = 0; l < 8; l++) {
-                float dp[8], hv[8];
-                unpack8(gblk[((8 * l + jb) * CB + cb) * 64 + lane], dp);
-                unpack8(sblk[((8 * l + jb) * CB + cb) * 64 + lane], hv);
 #pragma unroll
-                for (int e = 0; e < 8; e++) dm[e] += hv[e] != 0.0f ? dp[e] * hv[e] / (mval[e] * mval[e]) : 0.0f;
+            for (int k = 0; k < NT_FEAT; k++) {
+                const bf16x8 a = __builtin_bit_cast(bf16x8, u[(1 + k) * 64 + lane]);
+#pragma unroll
+                for (int cb = 0; cb < CB; cb++) macc[k % 2][cb] = mfma16<EP>(a, feat[cb].t[0][k / 2], macc[k % 2][cb]);
             }
-            gblk[((78 + jb) * CB + cb) * 64 + lane] = pack8(dm);
-            // d features: d f[c] += sum over this lane's 8 features of Wm[f][c] d m[f]
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const int f = 32 * jb + (e < 4 ? 4 * grp + e : 16 + 4 * grp + (e - 4));
-                const float *wr = wm + (size_t)f * F;
-                for (int t = 0; t < KF; t++)
-                    for (int q = 0; q < 32; q++) {
-                        const int c = map_feat[32 * t + q];
-                        if (c >= 0) dall[32 * t + q] = fmaf(wr[c], dm[e], dall[32 * t + q]);
-                    }
+            for (int cb = 0; cb < CB; cb++) {
+                float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int l = 0; l < 8; l++) {
+                    float dp[8], hv[8];
+                    unpack8(gblk[((8 * l + jb) * CB + cb) * 64 + lane], dp);
+                    unpack8(sblk[((8 * l + jb) * CB + cb) * 64 + lane], hv);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) acc[e] = fmaf(dp[e], hv[e], acc[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const float mv = macc[e >> 2][cb][e & 3];
+                    acc[e] = acc[e] != 0.0f ? acc[e] / (mv * mv) : 0.0f;
+                }
+                store_tile<EP>(acc, dm[cb], jb);
+                gblk[((78 + jb) * CB + cb) * 64 + lane] = __builtin_bit_cast(uint4, dm[cb].t[0][jb]);
             }
         }
-        // sum the four groups' shares (lanes col, col+16, col+32, col+48) and write the sample's feature columns
+        // d features = Wm^T d m: row blocks = feature positions
 #pragma unroll
-        for (int i = 0; i < KF * 32; i++) {
-            float s = dall[i];
-            s += __shfl_xor(s, 16, 64);
-            s += __shfl_xor(s, 32, 64);
-            dall[i] = s;
-        }
-        if (valid[cb] && grp == 0) {
-            float *go = g_x + (size_t)(block * 32 + 16 * cb + col) * C_in + P;
-            for (int i = 0; i < KF * 32; i++) {
-                const int c = map_feat[i];
-                if (c >= 0) go[c] = dall[i];
+        for (int jb = 0; jb < KF; jb++) {
+            const uint4 *u = bwd_tail + (size_t)(jb * 17) * 64;
+            f32x4 acc[2][CB];
+#pragma unroll
+            for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+                for (int cb = 0; cb < CB; cb++) acc[rt][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const bf16x8 a = __builtin_bit_cast(bf16x8, u[(1 + k) * 64 + lane]);
+#pragma unroll
+                for (int cb = 0; cb < CB; cb++) acc[k % 2][cb] = mfma16<EP>(a, dm[cb].t[0][k / 2], acc[k % 2][cb]);
+            }
+#pragma unroll
+            for (int cb = 0; cb < CB; cb++) {
+                if (!gx_row[cb]) continue;
+#pragma unroll
+                for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int c = map_feat[32 * jb + 16 * rt + 4 * grp + r];
+                        if (c >= 0) gx_row[cb][P + c] = acc[rt][cb][r];
+                    }
             }
         }
     }
@@ -405,18 +417,32 @@ __global__ __launch_bounds__(kWaves * 64, kWaves / 4) void train16_dw_kernel(
     }
     const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
     const unsigned img0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)&img[0][0][0];
+    // items = (tile, column block) of a block: a wave takes items wave, wave + 8, ... (at most 4); the tiles of
+    // block b + 1 are requested before block b is computed, so their HBM latency hides behind the MFMAs
+    const int items = (n_out + (job.in_kind == 0 ? n_in : 0)) * CB;
+    auto fetch_item = [&](long long b, int it) {
+        const int t = it / CB, cb = it % CB;
+        const bool is_out = t < n_out;
+        const int kt = is_out ? t : t - n_out;
+        return is_out ? grad[(((size_t)b * kGradTiles + job.out_tile0 + kt) * CB + cb) * 64 + lane]
+                      : stash[(((size_t)b * kStashTiles + job.in_tile0 + kt) * CB + cb) * 64 + lane];
+    };
+    uint4 pre[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (b0 < b1 && wave + 8 * i < items) pre[i] = fetch_item(b0, wave + 8 * i);
     for (long long b = b0; b < b1; b++) {
         const int buf = (int)((b - b0) & 1);
         char *im_out = img[buf][0], *im_in = img[buf][1];
-        // ---- stage the block's tiles: items = (tile, column block); image row = sample, 16 B at position 8 g of the k-tile
-        const int items = (n_out + (job.in_kind == 0 ? n_in : 0)) * CB;
-        for (int it = wave; it < items; it += kWaves) {
+        // ---- stage the block's tiles: image row = sample, 16 B at position 8 g of the k-tile
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int it = wave + 8 * i;
+            if (it >= items) continue;
             const int t = it / CB, cb = it % CB;
             const bool is_out = t < n_out;
             const int kt = is_out ? t : t - n_out;
-            const uint4 q = is_out ? grad[(((size_t)b * kGradTiles + job.out_tile0 + kt) * CB + cb) * 64 + lane]
-                                   : stash[(((size_t)b * kStashTiles + job.in_tile0 + kt) * CB + cb) * 64 + lane];
-            *reinterpret_cast<uint4 *>((is_out ? im_out : im_in) + (16 * cb + col) * kImgStride + kt * 64 + grp * 16) = q;
+            *reinterpret_cast<uint4 *>((is_out ? im_out : im_in) + (16 * cb + col) * kImgStride + kt * 64 + grp * 16) = pre[i];
         }
         if (job.in_kind != 0 && wave < CB) {            // operands rebuilt from the rows of x: one column block per wave
             const int cb = wave;
@@ -447,6 +473,9 @@ __global__ __launch_bounds__(kWaves * 64, kWaves / 4) void train16_dw_kernel(
             }
         }
         __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (b + 1 < b1 && wave + 8 * i < items) pre[i] = fetch_item(b + 1, wave + 8 * i);
         if (wave < n_out) {
             const unsigned a_out = img0 + (unsigned)(buf * 2) * kImgBytes, a_in = a_out + kImgBytes;
             bf16x8 A[2];
@@ -547,7 +576,8 @@ extern "C" size_t zest_mlp_train16_stash_bytes(const zest_mlp_desc *desc, int M)
 }
 extern "C" size_t zest_mlp_train16_work_bytes(const zest_mlp_desc *desc, int M) {
     if (!desc || M <= 0) return 0;
-    return sizes_of(M).grad_bytes + 2 * ZEST_P_COUNT * sizeof(float *);
+    const Sizes s = sizes_of(M);
+    return s.grad_bytes + s.side_bytes + 2 * ZEST_P_COUNT * sizeof(float *);
 }
 extern "C" size_t zest_mlp_train16_packed_bytes(const zest_mlp_desc *desc) { return desc ? zest::bwd_stream_bytes(*desc) : 0; }
 
@@ -584,7 +614,8 @@ extern "C" int zest_mlp_train16_bwd(const zest_mlp_desc *desc, const void *packe
     const uint4 *stash_tiles = (const uint4 *)stash;
     const uint2 *masks = (const uint2 *)((const char *)stash + s.tile_bytes);
     uint4 *grad = (uint4 *)work;
-    float **g_dev = (float **)((char *)work + s.grad_bytes);
+    float4 *pts_side = (float4 *)((char *)work + s.grad_bytes);
+    float **g_dev = (float **)((char *)work + s.grad_bytes + s.side_bytes);
     const int cus = cu_count();
     if (stages & 1) {
         const int units = zest::bwd_stream_units_of(d);
@@ -595,7 +626,7 @@ extern "C" int zest_mlp_train16_bwd(const zest_mlp_desc *desc, const void *packe
         ZEST_CHECK_ARG(units == bwd_stream_units(NTP, MODF ? NTF : 0), "zest_mlp_train16_bwd: stream of %d units, kernel expects %d", \
                        units, bwd_stream_units(NTP, MODF ? NTF : 0));                                          \
         hipLaunchKernelGGL((train16_data_kernel<NTP, MODF, NTF>), dim3(blocks), dim3(kWaves * 64), 0, st,      \
-                           (const uint4 *)packed_bwd, x, out, g_out, M, P, F, C_in, C_out, d.head, masks, t->map_pts, grad, g_x); \
+                           (const uint4 *)packed_bwd, x, out, g_out, M, P, F, C_in, C_out, d.head, masks, grad, pts_side); \
     } while (0)
         const int key = t->fwd.nt_pts * 10 + (mod ? t->fwd.nt_feat : 0);
         switch (key) {
@@ -612,15 +643,23 @@ extern "C" int zest_mlp_train16_bwd(const zest_mlp_desc *desc, const void *packe
         }
 #undef ZEST_DATA
     }
-    if ((stages & 2) && mod) {
+    if (stages & 2) {
         const long long n_blocks = ((long long)M + 31) / 32;
-        const float *wm = params[2 * ZEST_P_PTS_BIAS], *bm = params[2 * ZEST_P_PTS_BIAS + 1];
-        if (t->fwd.nt_feat == 2)
-            hipLaunchKernelGGL((train16_mod_kernel<2>), dim3(zest_div_up(n_blocks, 4)), dim3(256), 0, st, x, M, P, F, C_in, wm, bm,
-                               stash_tiles, grad, t->map_feat, g_x);
-        else
-            hipLaunchKernelGGL((train16_mod_kernel<4>), dim3(zest_div_up(n_blocks, 4)), dim3(256), 0, st, x, M, P, F, C_in, wm, bm,
-                               stash_tiles, grad, t->map_feat, g_x);
+        const uint4 *tail = (const uint4 *)packed_bwd + (size_t)zest::bwd_stream_units_of(d) * 64;
+#define ZEST_FIN(NTP, NTF)                                                                                       \
+    hipLaunchKernelGGL((train16_finish_kernel<NTP, NTF>), dim3(zest_div_up(n_blocks, 4)), dim3(256), 0, st, x, M, P, F, \
+                       C_in, tail, stash_tiles, grad, (const float4 *)pts_side, t->map_pts, t->map_feat, g_x)
+        const int key = t->fwd.nt_pts * 10 + (mod ? t->fwd.nt_feat : 0);
+        switch (key) {
+            case 40: ZEST_FIN(4, 0); break;
+            case 42: ZEST_FIN(4, 2); break;
+            case 44: ZEST_FIN(4, 4); break;
+            case 60: ZEST_FIN(6, 0); break;
+            case 62: ZEST_FIN(6, 2); break;
+            case 64: ZEST_FIN(6, 4); break;
+            default: break;
+        }
+#undef ZEST_FIN
     }
     if (stages & 4) {
         hipError_t e = hipMemcpyAsync(g_dev, g_params, 2 * ZEST_P_COUNT * sizeof(float *), hipMemcpyHostToDevice, st);

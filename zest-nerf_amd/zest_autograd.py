@@ -12,7 +12,9 @@ MLP).  Gradients exist exactly where the reference's training graph has them (SU
 
   VolumeCostFn, HomoWarpFn   d/d(feature maps) of the MVS plane sweep (scatter-add through the bilinear taps).
 
-The training path computes in fp32 whatever `precision` says (the bf16 engine is inference only).
+Two training modes of the MLP: fp32 (MlpFn: rocBLAS sgemm + fused elementwise kernels, the 1e-3 parity
+mode; `--precision 32`) and bf16 on the hand-written MFMA kernels (MlpFn16; `--precision 16`).  The other
+stages compute in fp32 in both.
 """
 import torch
 from torch.autograd import Function
@@ -70,6 +72,37 @@ class MlpFn(Function):
         return (g_x.view(*ctx.lead, -1) if g_x is not None else None, None, None, *gp)
 
 
+class MlpFn16(Function):
+    """bf16 training path: forward and backward entirely on the hand-written MFMA kernels
+    (zest_mlp_train16_*): engine forward with activation stash; data / modulation / weight-gradient
+    kernels.  fp32 parameters in, fp32 gradients out; 'v0' nets."""
+
+    @staticmethod
+    def forward(ctx, x, desc, slots, *params):
+        table = [None] * (2 * zest_hip.P_COUNT)
+        for i, s in enumerate(slots):
+            table[2 * s], table[2 * s + 1] = params[2 * i].detach(), params[2 * i + 1].detach()
+        lead = x.shape[:-1]
+        x2 = x.detach().reshape(-1, x.shape[-1]).contiguous()
+        out, stash = zest_hip.mlp_train16_fwd(desc, zest_hip.mlp_pack(desc, zest_hip.PREC_BF16, table), x2)
+        ctx.desc, ctx.slots, ctx.lead = desc, slots, lead
+        ctx.save_for_backward(x2, stash, out, *params)
+        return out.view(*lead, desc.out_ch)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x2, stash, out, *params = ctx.saved_tensors
+        table = [None] * (2 * zest_hip.P_COUNT)
+        for i, s in enumerate(ctx.slots):
+            table[2 * s], table[2 * s + 1] = params[2 * i].detach(), params[2 * i + 1].detach()
+        g_x, grads, _ = zest_hip.mlp_train16_bwd(ctx.desc, zest_hip.mlp_train16_pack_bwd(ctx.desc, table), table, x2,
+                                                 stash, out, g_out.reshape(-1, ctx.desc.out_ch).contiguous())
+        gp = []
+        for s in ctx.slots:
+            gp += [grads[2 * s], grads[2 * s + 1]]
+        return (g_x.view(*ctx.lead, -1) if ctx.needs_input_grad[0] else None, None, None, *gp)
+
+
 class CompositeFn(Function):
     @staticmethod
     def forward(ctx, raw, z, dirs, noise, noise_std, white_bkgd, is_dists=False):
@@ -124,10 +157,11 @@ class Prob2dFn(Function):
         return None, -(g[:, None] * w)
 
 
-def mlp_apply(net, x, time_codes=None):
+def mlp_apply(net, x, time_codes=None, bf16=False):
     """Training forward of a zest networks.MVSNeRF on x [..., C_in] with autograd.  time_codes: the
     frame's latent code for a net with time-code channels (folded into layer 0 / 5 biases with
-    differentiable torch ops: gradients reach the code and the full-width weights)."""
+    differentiable torch ops: gradients reach the code and the full-width weights).  bf16: the fast
+    training mode (MlpFn16, 'v0' nets); otherwise the fp32 parity path (MlpFn)."""
     mod = net.nerf
     desc = mod._desc()
     named = mod.effective_parameters(time_codes)
@@ -142,6 +176,8 @@ def mlp_apply(net, x, time_codes=None):
     for name, slot in extra:
         slots.append(slot)
         params += [named[name + ".weight"], named[name + ".bias"]]
+    if bf16 and desc.net_type == 0:
+        return MlpFn16.apply(x, desc, tuple(slots), *params)
     return MlpFn.apply(x, desc, tuple(slots), *params)
 
 

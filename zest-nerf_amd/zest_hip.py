@@ -532,7 +532,13 @@ def mlp_train16_bwd(desc, packed_bwd, params, x, stash, out, g_out, stages=7, wo
     if work is None or work.numel() < need:
         work = torch.empty(need, device=x.device, dtype=torch.uint8)
     keep = [(_dev(p, "param") if p is not None else None) for p in params]
-    grads = [(torch.zeros_like(p) if p is not None else None) for p in keep]
+    # the gradients are accumulated with atomics: one zero-filled buffer (one fill launch), views into it
+    sizes = [(p.numel() + 3) // 4 * 4 if p is not None else 0 for p in keep]
+    flat = torch.zeros(sum(sizes), device=x.device, dtype=torch.float32)
+    grads, off = [], 0
+    for p, n in zip(keep, sizes):
+        grads.append(flat[off:off + p.numel()].view(p.shape) if p is not None else None)
+        off += n
     g_x = torch.zeros_like(x)
     _check(lib().zest_mlp_train16_bwd(C.byref(desc), _ptr(packed_bwd), _ptr_table(keep), _ptr(x), M, _ptr(stash), _ptr(out),
                                       _ptr(g_out), _ptr(work), _ptr(g_x), _ptr_table(grads), int(stages), _stream(x)),

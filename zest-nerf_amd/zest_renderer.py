@@ -220,9 +220,11 @@ def rendering(args, rays_pts, rays_ndc, depth_candidates, rays_dir,
 
     mlp_prec = inference_precision(prec, args)
 
+    train16 = prec in (zest_hip.PREC_BF16, zest_hip.PREC_F16)       # --precision 16: bf16 MFMA training kernels
+
     def mlp(net, x, tc=None):
         if train:
-            return za.mlp_apply(net, x, tc)
+            return za.mlp_apply(net, x, tc, bf16=train16)
         return zest_hip.mlp_fwd(net.desc(), mlp_prec, net.packed(mlp_prec, tc), x)
 
     def encode(views, volume, ndc3, t=None):

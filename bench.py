@@ -346,7 +346,7 @@ def main():
         return float(tmax.item())
 
     def kernel_ms():
-        """per-launch time of the fused kernel from HIP events on the launch stream"""
+        """per-launch time of the fused kernel from HIP events on the launch stream (median of <= 50 launches)"""
         evs = []
         with torch.no_grad():
             for _ in range(min(a.steps, 50)):
@@ -356,7 +356,7 @@ def main():
                 e1.record()
                 evs.append((e0, e1))
             torch.cuda.synchronize()
-        return float(np.mean([x.elapsed_time(y) for x, y in evs]))
+        return float(np.median([x.elapsed_time(y) for x, y in evs]))      # median: one pre-empted launch must not skew it
 
     el = timed_loop()
     if a.dry:

@@ -207,6 +207,13 @@ int zest_build_rays_fwd(const float *xs, const float *ys, const float *t_rand, i
                         int pad, int W, int H, float *rays_dir, float *depth, float *pts, float *ndc,
                         void *stream);
 
+/* Hierarchical resampling (`sample_pdf` of BASELINE.json's north_star; the reference itself has no such
+ * function - a build extension, canonical NeRF inverse-CDF semantics, parity unpinned).  bins [R, n_bins + 1]
+ * ascending bin edges, weights [R, n_bins] >= 0, u [R, n_samples] in [0, 1) or NULL (deterministic:
+ * linspace(0, 1, n_samples)) -> samples [R, n_samples]: ascending when u is, inside [bins[0], bins[n_bins]]. */
+int zest_sample_pdf_fwd(const float *bins, const float *weights, const float *u, int R, int n_bins,
+                        int n_samples, float *samples, void *stream);
+
 /* get_ndc_coordinate (reference utils.py:232-288): world pts [M,3] -> (u, v, z) normalised by
  * inv_scale = (inv_w, inv_h) and [near, far] (or inverse depth when lindisp), with the padded
  * feature-map rescale when pad > 0.  w2c [4,4] (device) may be NULL (points already in the

@@ -478,6 +478,30 @@ def volume_cost(imgs, feats, proj_mats, depth, pad=0):
     return img_feat, masks
 
 
+def graf_patch_pixels(H, W, patch_size, step, scale_anneal=-1, min_scale=0.25, max_scale=1.0):
+    """Pixel (x, y) indices of GRAF's variable patch.  Restates patch_ray_sampler and the variable_patches branch
+    of get_rays_mvs, /root/reference/utils.py:102-131, 157-170: a patch_size^2 lattice over [-1, 1]^2 scaled by
+    s ~ U(min_scale', max_scale) (min_scale' annealed with the step) and shifted by +-U(0, 1 - s) per axis - draws in
+    that order from torch's CPU generator - then mapped to pixels by bilinear sampling of the coordinate ramps
+    and truncation to int."""
+    import math
+    lin = torch.linspace(-1, 1, patch_size)
+    if scale_anneal > 0:
+        min_scale = min(0.9, max(min_scale, max_scale * math.exp(-(step // 1000 * 3) * scale_anneal)))
+    s = torch.Tensor(1).uniform_(min_scale, max_scale)
+    gx = (lin[None, :] * s).expand(patch_size, patch_size)
+    gy = (lin[:, None] * s).expand(patch_size, patch_size)
+    room = 1 - s.item()
+    gx = gx + torch.Tensor(1).uniform_(0, room) * (torch.randint(2, (1,)).float() - 0.5) * 2
+    gy = gy + torch.Tensor(1).uniform_(0, room) * (torch.randint(2, (1,)).float() - 0.5) * 2
+    grid = torch.stack([gx, gy], -1)[None]
+    ramp_x = torch.arange(W, dtype=torch.float32)[None, :].expand(H, W)[None, None]
+    ramp_y = torch.arange(H, dtype=torch.float32)[:, None].expand(H, W)[None, None]
+    xs = F.grid_sample(ramp_x, grid, mode="bilinear", align_corners=True).reshape(-1).int()
+    ys = F.grid_sample(ramp_y, grid, mode="bilinear", align_corners=True).reshape(-1).int()
+    return xs, ys
+
+
 # ------------------------------------------------ loss-side reductions (8(f) row 4)
 def distortion_loss(ray_weights, t_vals):
     """ray_weights [R,S], t_vals [1,S] or [R,S] -> scalar.

@@ -199,6 +199,8 @@ CASES = {
     "rays_dy_motion": dict(kind="rays", seed=53, pad=2, stratified=True, torch_seed=11, scene_flow=True,
                            num_extra_samples=8),
     "rays_patches": dict(kind="rays", seed=54, pad=2, stratified=True, torch_seed=5, patch_size=4),
+    "rays_graf_patches": dict(kind="rays", seed=55, pad=2, stratified=True, torch_seed=9, patch_size=4, R=16,
+                              variable_patches=True, scale_anneal=0.0025, step=3000),      # GRAF: N_rays = patch_size^2
     "homo_warp": dict(kind="homo_warp", seed=63, pad=3),
     "loss_side": dict(kind="loss_side", seed=71),
     "render_static_mvs": dict(kind="render", seed=31, use_mvs=True),
@@ -263,7 +265,7 @@ def build(case):
     if k == "homo_warp":
         return cost_inputs(c["seed"], V=c.get("V", 3), pad=c["pad"])
     if k == "rays":
-        return rays_inputs(c["seed"])
+        return rays_inputs(c["seed"], R=c.get("R", 48))
     if k in ("render", "render_grad"):
         return render_inputs(c["seed"], use_mvs=c.get("use_mvs", True),
                              scene_flow=c.get("scene_flow", False),

@@ -62,7 +62,10 @@ def rays_pixels(c, inp):
     H, W, R = inp["H"], inp["W"], inp["R"]
     torch.manual_seed(c.get("torch_seed", 0))
     ps = c.get("patch_size", -1)
-    if ps > 0:
+    if c.get("variable_patches", False):
+        xs, ys = zo.graf_patch_pixels(H, W, ps, c.get("step", 0), c.get("scale_anneal", -1))
+        xs, ys = xs.float(), ys.float()
+    elif ps > 0:
         n = R // (ps * ps)
         xb, yb = torch.randint(0, W - ps, (n,)), torch.randint(0, H - ps, (n,))
         ar = torch.arange(ps, dtype=torch.float32)

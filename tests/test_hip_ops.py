@@ -221,3 +221,36 @@ def test_forward_alpha_matches_reference(hip, case, exact, monkeypatch):
     assert a.shape == (1, 64, 1)
     close(a[0], gold["alpha_only"], name=case + "/forward_alpha")
     close(y[0], gold["y"], name=case + "/forward after forward_alpha")
+
+
+def test_sample_pdf_inverse_cdf_properties(hip):
+    """sample_pdf (named by BASELINE.json's north_star; the reference has no counterpart: parity unpinned):
+    against a float64 numpy inverse CDF, and by its properties - samples ascending for ascending quantiles,
+    inside the bins, concentrated where the weight is, uniform weights give back evenly spaced depths."""
+    import zest_hip
+    import zest_utils
+    g = gc.zs.rng(321)
+    for R, Nb, Ns in ((37, 127, 64), (5, 63, 200), (3, 1, 9), (2, 300, 128)):
+        edges = np.sort(g.uniform(2.0, 6.0, size=(R, Nb + 1)).astype(np.float32), -1)
+        w = g.uniform(0, 1, size=(R, Nb)).astype(np.float32) ** 4
+        w[0, : Nb // 2] = 0.0                                                  # a dead half
+        u = np.sort(g.uniform(0, 1, size=(R, Ns)).astype(np.float32), -1)
+        got = zest_hip.sample_pdf(G(edges), G(w), u=G(u)).cpu().numpy()
+        pdf = (w.astype(np.float64) + 1e-5) / (w.astype(np.float64) + 1e-5).sum(-1, keepdims=True)
+        cdf = np.concatenate([np.zeros((R, 1)), np.cumsum(pdf, -1)], -1)
+        want = np.empty_like(got, dtype=np.float64)
+        for r in range(R):
+            idx = np.searchsorted(cdf[r], u[r].astype(np.float64), side="right")
+            below, above = np.maximum(idx - 1, 0), np.minimum(idx, Nb)
+            den = cdf[r, above] - cdf[r, below]
+            den = np.where(den < 1e-5, 1.0, den)
+            want[r] = edges[r, below] + (u[r] - cdf[r, below]) / den * (edges[r, above] - edges[r, below])
+        # a quantile that falls within fp32 rounding of a cdf knot may pick the neighbouring bin: continuous there
+        assert np.abs(got - want).max() < 2e-3 * (edges.max() - edges.min()), np.abs(got - want).max()
+        assert (np.diff(got, axis=-1) >= -1e-5).all()
+        assert (got >= edges[:, :1] - 1e-6).all() and (got <= edges[:, -1:] + 1e-6).all()
+        if Nb > 1:
+            assert (got[0] >= edges[0, Nb // 2] - 1e-3).mean() > 0.97                # mass only in the live half
+    z = np.linspace(2, 6, 65, dtype=np.float32)[None]
+    det = zest_utils.sample_pdf(G(z), torch.ones(1, 64, device="cuda"), 33, det=True)
+    close(det[0], np.linspace(2, 6, 33), atol=1e-4, rtol=0, name="uniform weights")

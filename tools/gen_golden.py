@@ -202,7 +202,8 @@ def run_rays(U, c, inp, wrap=T):
                             stratified=c.get("stratified", True), pad=c.get("pad", 0),
                             chunk=c.get("chunk", -1), idx=c.get("idx", -1), val=not c.get("isRandom", True),
                             isRandom=c.get("isRandom", True), patch_size=c.get("patch_size", -1),
-                            scene_flow=sf,
+                            variable_patches=c.get("variable_patches", False), scale_anneal=c.get("scale_anneal", -1),
+                            step=c.get("step", 0), scene_flow=sf,
                             flow_fwd=wrap(inp["flow_fwd"]) if sf else None, flow_bwd=wrap(inp["flow_bwd"]) if sf else None,
                             mask_fwd=wrap(inp["mask_fwd"]) if sf else None, mask_bwd=wrap(inp["mask_bwd"]) if sf else None,
                             num_extra_samples=c.get("num_extra_samples", 0),

@@ -86,7 +86,68 @@ __global__ void ndc_kernel(const float *__restrict__ w2c, const float *__restric
     out[3 * m] = o[0], out[3 * m + 1] = o[1], out[3 * m + 2] = o[2];
 }
 
+// Hierarchical (coarse -> fine) resampling, the `sample_pdf` BASELINE.json's north_star names.  The
+// reference has no such function ("Read this first" 1): this is the canonical NeRF inverse-CDF
+// sampler, a build extension with unpinned parity, tested by its properties and against a numpy
+// inverse CDF.  One wave per ray: pdf = (w + 1e-5) / sum, its running sum by a shuffle scan into LDS
+// (cdf[0] = 0), then every fine sample finds its bin by binary search in LDS and interpolates inside it.
+constexpr int kMaxBins = 512;
+
+__global__ __launch_bounds__(256) void sample_pdf_kernel(const float *__restrict__ bins, const float *__restrict__ weights,
+                                                         const float *__restrict__ u_in, int R, int Nb, int Ns,
+                                                         float *__restrict__ out) {
+    __shared__ float cdf_s[4][kMaxBins + 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wv;
+    if (r >= R) return;                                    // wave-uniform
+    float *cdf = cdf_s[wv];
+    const float *w = weights + (size_t)r * Nb, *b = bins + (size_t)r * (Nb + 1);
+    float total = 0.0f;
+    for (int i = lane; i < Nb; i += 64) total += w[i] + 1e-5f;
+    total = wave_sum(total);
+    float carry = 0.0f;
+    if (lane == 0) cdf[0] = 0.0f;
+    for (int i0 = 0; i0 < Nb; i0 += 64) {
+        const int i = i0 + lane;
+        float v = i < Nb ? (w[i] + 1e-5f) / total : 0.0f;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const float o = __shfl_up(v, d, 64);
+            if (lane >= d) v += o;
+        }
+        if (i < Nb) cdf[i + 1] = carry + v;
+        carry += __shfl(v, 63, 64);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): the wave's own LDS writes are visible to its reads
+    for (int j = lane; j < Ns; j += 64) {
+        const float u = u_in ? u_in[(size_t)r * Ns + j] : (Ns > 1 ? (float)j / (float)(Ns - 1) : 0.5f);
+        int lo = 0, hi = Nb + 1;                           // first index with cdf[idx] > u  (searchsorted, right = True)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid] > u) hi = mid;
+            else lo = mid + 1;
+        }
+        const int below = max(lo - 1, 0), above = min(lo, Nb);
+        const float c0 = cdf[below], c1 = cdf[above];
+        float den = c1 - c0;
+        if (den < 1e-5f) den = 1.0f;
+        const float t = (u - c0) / den;
+        out[(size_t)r * Ns + j] = b[below] + t * (b[above] - b[below]);
+    }
+}
+
 }  // namespace
+
+extern "C" int zest_sample_pdf_fwd(const float *bins, const float *weights, const float *u, int R, int n_bins,
+                                   int n_samples, float *samples, void *stream) {
+    ZEST_CHECK_ARG(bins && weights && samples, "zest_sample_pdf_fwd: null argument");
+    ZEST_CHECK_ARG(R >= 0 && n_bins >= 1 && n_bins <= kMaxBins && n_samples >= 1,
+                   "zest_sample_pdf_fwd: bad shape R=%d bins=%d samples=%d (at most %d bins)", R, n_bins, n_samples, kMaxBins);
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(sample_pdf_kernel, dim3(zest_div_up(R, 4)), dim3(256), 0, (hipStream_t)stream, bins, weights, u, R,
+                       n_bins, n_samples, samples);
+    ZEST_RETURN_LAUNCH("zest_sample_pdf_fwd");
+}
 
 extern "C" int zest_build_rays_fwd(const float *xs, const float *ys, const float *t_rand, int R, int S,
                                    const float *k_tgt, const float *c2w_tgt, const float *w2c_ref,

@@ -71,6 +71,7 @@ _SIGS = {
                              _vp, _vp, _vp, _vp]),
     "zest_build_rays_fwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i,
                                  _vp, _vp, _vp, _vp, _vp]),
+    "zest_sample_pdf_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "zest_ndc_fwd": (_i, [_vp, _i, _vp, _vp, _f, _f, _f, _f, _i, _i, _vp, _vp]),
     "zest_composite_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "zest_composite_blend_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -405,6 +406,19 @@ def build_rays(xs, ys, t_rand, S, k_tgt, c2w_tgt, w2c_ref, k_ref, nf_tgt, nf_ref
                                      int(pad), int(W), int(H), _ptr(d), _ptr(z), _ptr(pts), _ptr(ndc),
                                      _stream(xs)), "zest_build_rays_fwd")
     return d, z, pts, ndc
+
+
+def sample_pdf(bins, weights, n_samples=None, u=None):
+    """bins [R, Nb+1], weights [R, Nb], u [R, Ns] (or None + n_samples: deterministic) -> samples [R, Ns]."""
+    bins, weights, u = _dev(bins, "bins"), _dev(weights, "weights"), _dev(u, "u")
+    R, Nb = weights.shape
+    if tuple(bins.shape) != (R, Nb + 1):
+        raise RuntimeError("zest_hip.sample_pdf: bins %s for weights %s" % (tuple(bins.shape), tuple(weights.shape)))
+    Ns = u.shape[1] if u is not None else int(n_samples)
+    out = torch.empty(R, Ns, device=bins.device, dtype=torch.float32)
+    _check(lib().zest_sample_pdf_fwd(_ptr(bins), _ptr(weights), _ptr(u), R, Nb, Ns, _ptr(out), _stream(bins)),
+           "zest_sample_pdf_fwd")
+    return out
 
 
 def ndc_coordinate(pts, w2c, k, inv_w, inv_h, near, far, pad=0, lindisp=False):

@@ -14,7 +14,7 @@ import zest_hip
 
 __all__ = ["homo_warp", "index_point_feature", "build_color_volume", "volume_channels_last",
            "images_channels_last", "get_ndc_coordinate", "get_rays_mvs", "build_rays_base",
-           "build_rays", "build_rays_dy"]
+           "build_rays", "build_rays_dy", "sample_pdf", "patch_ray_sampler", "projection_from_ndc"]
 
 _CL_CACHE = {}
 _CL_CACHE_MAX = 8
@@ -144,6 +144,43 @@ def get_ndc_coordinate(w2c_ref, intrinsic_ref, point_samples, inv_scale, near=2,
     return out.view(1, R, S, 3)
 
 
+def sample_pdf(bins, weights, N_samples, det=False):
+    """Importance resampling of depth candidates from the coarse pass's compositing weights (the `sample_pdf`
+    BASELINE.json's north_star names).  The reference has none (`--N_importance` is parsed, `opt.py:161`, and a
+    fine net is built, `train.py:143-148`, but no renderer call receives it): canonical NeRF inverse-CDF
+    semantics, HIP kernel zest_sample_pdf_fwd, parity unpinned (tests: numpy inverse CDF + properties).
+    bins [..., Nb+1] bin edges (e.g. the midpoints of the coarse depths), weights [..., Nb]; det: evenly spaced
+    quantiles instead of torch.rand draws.  -> [..., N_samples] new depths (detached: data for the fine pass)."""
+    lead = weights.shape[:-1]
+    b2, w2 = bins.detach().reshape(-1, bins.shape[-1]), weights.detach().reshape(-1, weights.shape[-1])
+    u = None if det else _draw_uniform((w2.shape[0], N_samples), w2.device)
+    return zest_hip.sample_pdf(b2, w2, N_samples, u).view(*lead, N_samples)
+
+
+def patch_ray_sampler(patch_size, step, random_shift=True, random_scale=True, min_scale=0.25, max_scale=1.,
+                      scale_anneal=-1):
+    """GRAF's variable patch: a patch_size x patch_size lattice over [-1, 1]^2, randomly scaled (the smallest
+    scale annealed towards the whole image with the step) and shifted so it stays inside (reference
+    utils.py:102-131).  -> [patch_size, patch_size, 2] grid_sample positions (x, y).  The random draws are the
+    reference's own CPU calls in the reference's order (scale; then per axis offset magnitude, offset sign), so a
+    run seeded like the reference samples the same patches."""
+    import math
+    lin = torch.linspace(-1, 1, patch_size)
+    rows, cols = lin[:, None, None].expand(-1, patch_size, 1), lin[None, :, None].expand(patch_size, -1, 1)
+    if scale_anneal > 0:
+        floor = max(min_scale, max_scale * math.exp(-(step // 1000 * 3) * scale_anneal))
+        min_scale = min(0.9, floor)
+    scale = torch.ones(1)
+    if random_scale:
+        scale = torch.Tensor(1).uniform_(min_scale, max_scale)
+    x, y = cols * scale, rows * scale
+    if random_shift:
+        room = 1 - scale.item()
+        x = x + torch.Tensor(1).uniform_(0, room) * (torch.randint(2, (1,)).float() - 0.5) * 2
+        y = y + torch.Tensor(1).uniform_(0, room) * (torch.randint(2, (1,)).float() - 0.5) * 2
+    return torch.cat([x, y], dim=2)
+
+
 def get_rays_mvs(H, W, intrinsic, c2w, N_rays=1024, isRandom=True, chunk=-1, idx=-1, N_patches=None,
                  patch_size=-1, scale_anneal=-1, step=0, variable_patches=False, num_extra_samples=0,
                  motion_coords=None):
@@ -151,9 +188,16 @@ def get_rays_mvs(H, W, intrinsic, c2w, N_rays=1024, isRandom=True, chunk=-1, idx
     (reference utils.py:133-230).  -> rays_o [N,3], rays_d [N,R,3], pixel_coordinates [N,2,R]."""
     device = c2w.device
     if variable_patches:
-        raise NotImplementedError("get_rays_mvs: GRAF variable patches (adversarial SVS mode) are "
-                                  "outside the rendering path and not implemented")
-    if N_patches:
+        # GRAF discriminator patches (utils.py:157-170): the lattice positions are turned into pixel indices by
+        # sampling the coordinate ramps bilinearly and truncating - done with the very same host ops so the
+        # truncation falls where the reference's does
+        grid = patch_ray_sampler(patch_size, step, scale_anneal=scale_anneal)[None]
+        row_ramp = torch.linspace(0, H - 1, H)[:, None].expand(H, W)[None, None]
+        col_ramp = torch.linspace(0, W - 1, W)[None, :].expand(H, W)[None, None]
+        gs = torch.nn.functional.grid_sample
+        xs = gs(col_ramp, grid, mode="bilinear", align_corners=True).reshape(-1).int().to(device)
+        ys = gs(row_ramp, grid, mode="bilinear", align_corners=True).reshape(-1).int().to(device)
+    elif N_patches:
         xb, yb = torch.randint(0, W - patch_size, (N_patches,)), torch.randint(0, H - patch_size, (N_patches,))
         ar = torch.arange(patch_size, dtype=torch.float32)
         ys = (yb.float()[:, None, None] + ar[None, :, None]).expand(-1, -1, patch_size).reshape(-1)

@@ -63,11 +63,15 @@ constexpr int kChunk = ZEST_CHUNK, kSlots = ZEST_SLOTS, kRingUnits = kChunk * kS
 static_assert(kStreamAlign % kRingUnits == 0, "stream padding must be a multiple of the ring size");
 static_assert(kSlots >= kAhead + 1, "a slot is refilled while the previous chunk may still be read");
 
+#ifndef ZEST_ISSUERS
+#define ZEST_ISSUERS 8     // waves of the workgroup that issue the weight DMA (8: every wave its share; 4: waves 0-3,
+#endif                     // one per SIMD, take all of it and their SIMD partners 4-7 none - measured in DESIGN.md section 4)
 template <int NW, int UNITS_A, int UNITS_B>
 struct RingTiles {
-    static constexpr int kPieces = kChunk / NW;             // DMA pieces per wave per chunk
+    static constexpr int kIssuers = ZEST_ISSUERS < NW ? ZEST_ISSUERS : NW;
+    static constexpr int kPieces = kChunk / kIssuers;       // DMA pieces per issuing wave per chunk
     static constexpr int kChunksA = UNITS_A / kChunk, kChunks = (UNITS_A + UNITS_B) / kChunk;
-    static_assert(kChunk % NW == 0 && UNITS_A % kRingUnits == 0 && UNITS_B % kRingUnits == 0, "");
+    static_assert(kChunk % kIssuers == 0 && UNITS_A % kRingUnits == 0 && UNITS_B % kRingUnits == 0, "");
     char *ring;            // LDS, kRingUnits KiB, 16-byte aligned
     gptr_u4 src_a, src_b;  // the two nets' streams (src_b unused when UNITS_B == 0)
     int lane, grp, wave;   // grp = lane >> 4; wave: provably uniform (readfirstlane)
@@ -92,6 +96,7 @@ struct RingTiles {
     // and the chunk's byte offset is made opaque so the 64-bit adds stay here instead of being
     // hoisted out of the pass loop for all chunks at once (which spills SGPRs to VGPR lanes).
     __device__ __forceinline__ void issue(int chunk) const {      // chunk: compile-time after unrolling
+        if (kIssuers < NW && wave >= kIssuers) return;             // wave-uniform: a scalar branch
         const int c = chunk % kChunks;
         unsigned off = (unsigned)((c < kChunksA ? c : c - kChunksA) * kChunk * 1024);
         asm volatile("" : "+s"(off));

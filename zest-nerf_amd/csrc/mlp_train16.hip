@@ -427,10 +427,12 @@ __global__ __launch_bounds__(kWaves * 64, kWaves / 4) void train16_dw_kernel(
         return is_out ? grad[(((size_t)b * kGradTiles + job.out_tile0 + kt) * CB + cb) * 64 + lane]
                       : stash[(((size_t)b * kStashTiles + job.in_tile0 + kt) * CB + cb) * 64 + lane];
     };
-    uint4 pre[4];
+    uint4 pre[4], pre2[4];                 // tiles of block b and of block b + 1 (requested two blocks ahead of their use)
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 4; i++) {
         if (b0 < b1 && wave + 8 * i < items) pre[i] = fetch_item(b0, wave + 8 * i);
+        if (b0 + 1 < b1 && wave + 8 * i < items) pre2[i] = fetch_item(b0 + 1, wave + 8 * i);
+    }
     for (long long b = b0; b < b1; b++) {
         const int buf = (int)((b - b0) & 1);
         char *im_out = img[buf][0], *im_in = img[buf][1];
@@ -474,8 +476,10 @@ __global__ __launch_bounds__(kWaves * 64, kWaves / 4) void train16_dw_kernel(
         }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-            if (b + 1 < b1 && wave + 8 * i < items) pre[i] = fetch_item(b + 1, wave + 8 * i);
+        for (int i = 0; i < 4; i++) {
+            pre[i] = pre2[i];
+            if (b + 2 < b1 && wave + 8 * i < items) pre2[i] = fetch_item(b + 2, wave + 8 * i);
+        }
         if (wave < n_out) {
             const unsigned a_out = img0 + (unsigned)(buf * 2) * kImgBytes, a_in = a_out + kImgBytes;
             bf16x8 A[2];
@@ -667,7 +671,9 @@ extern "C" int zest_mlp_train16_bwd(const zest_mlp_desc *desc, const void *packe
             zest_set_error("zest_mlp_train16_bwd: uploading the gradient pointers: %s", hipGetErrorString(e));
             return (int)e;
         }
-        int wg_per_job = (2 * cus) / t->n_jobs;
+        // one resident workgroup per CU (128 accumulator registers per lane): more workgroups per job would only
+        // run in a second round and add their 256 KB of gradient atomics each
+        int wg_per_job = cus / t->n_jobs;
         if (wg_per_job < 1) wg_per_job = 1;
         const long long n_blocks = ((long long)M + 31) / 32;
         if (wg_per_job > n_blocks) wg_per_job = (int)n_blocks;

@@ -52,7 +52,7 @@ def oracle_grads(inp, x, gw, bf16_operands=True):
     return y.detach().numpy(), xt.grad.numpy(), {k: (v.grad.numpy() if v.grad is not None else None) for k, v in state.items()}
 
 
-@pytest.mark.parametrize("M", [64, 300])
+@pytest.mark.parametrize("M", [64, 300, 1, 31])       # whole blocks, ragged, fewer samples than one block of 32
 @pytest.mark.parametrize("case", V0_CASES)
 def test_train16_forward_and_backward_match_the_oracle(hip, case, M):
     zh, inp, desc, tab = _mlp_setup(case)
@@ -85,7 +85,8 @@ def test_train16_forward_and_backward_match_the_oracle(hip, case, M):
             got = grads[2 * slot + j].cpu().numpy()
             assert got.shape == want.shape
             e = rel(got, want)
-            assert e < 5e-2, "%s.%s: relative L2 error %.3g" % (names[slot], kind, e)
+            # (a single sample: every tensor is one outer product of bf16-rounded factors)
+            assert e < (5e-2 if M > 1 else 8e-2), "%s.%s: relative L2 error %.3g" % (names[slot], kind, e)
             checked += 1
     assert checked >= 24
 

@@ -333,6 +333,10 @@ size_t zest_render_fused_workspace(int R, int S);
  * 1 = dense passes + combine launch, 2 = ray-aligned passes wherever a ray fits one pass.
  * Results are identical; a knob for tests and measurements. */
 int zest_render_fused_set_passes(int shape);
+/* What zest_render_fused_fwd will do for R rays of S samples on a device of `cus` compute units (0: the
+ * current device): *rays_per_pass > 0 = ray-aligned passes of that many whole rays, finished in the
+ * kernel; 0 = dense passes + the combine launch; *n_pass = workgroup passes.  Host arithmetic only. */
+int zest_render_fused_pass_shape(int R, int S, int precision, int cus, int *rays_per_pass, int *n_pass);
 
 int zest_render_fused_fwd(const float *ndc, const float *pts, const float *z,
                           const float *rays_dir, int R, int S,

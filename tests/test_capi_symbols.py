@@ -2,6 +2,7 @@
 import ctypes
 import os
 import re
+import sys
 
 import pytest
 
@@ -55,3 +56,19 @@ def test_library_is_not_older_than_its_sources():
         glob.glob(os.path.join(pkg, "csrc", "*.h")) + [os.path.join(ROOT, "include", "zest_render.h")]
     newest = max(srcs, key=os.path.getmtime)
     assert os.path.getmtime(lib) >= os.path.getmtime(newest), "libzest_hip.so is older than %s: rebuild" % newest
+
+
+def test_fused_pass_shapes_for_the_baseline_batches():
+    """Host arithmetic of the fused renderer's pass shape (no GPU call: cus given).  The headline batch and the
+    strong-scaled configs[3] shard (512 rays x 192 samples per GPU: 6 blocks per ray) finish their rays in the kernel
+    (no block records in HBM, no second launch); the full 4096 x 192 batch on one GPU takes dense passes, where
+    ray-aligned ones would cost 16 rounds of passes instead of 12."""
+    sys.path.insert(0, os.path.join(ROOT, "zest-nerf_amd"))
+    import zest_hip as zh
+    assert zh.fused_pass_shape(1024, 128, zh.PREC_BF16, 256) == (2, 512)          # 4 blocks per ray: 2 rays per pass
+    assert zh.fused_pass_shape(1024, 128, zh.PREC_F16X3, 256) == (1, 1024)        # 16-sample blocks: 8 per ray
+    assert zh.fused_pass_shape(512, 192, zh.PREC_BF16, 256) == (1, 512)           # 6 of 8 waves busy, 2 rounds either way
+    assert zh.fused_pass_shape(4096, 192, zh.PREC_BF16, 256) == (0, 3072)         # dense: 12 rounds instead of 16
+    assert zh.fused_pass_shape(8192, 128, zh.PREC_F16, 256) == (2, 4096)
+    assert zh.fused_pass_shape(7, 300, zh.PREC_BF16, 256) == (0, 9)               # 10 blocks per ray: more than a pass
+    assert zh.fused_pass_shape(0, 64, zh.PREC_BF16, 256) == (4, 0)

@@ -70,6 +70,32 @@ extern "C" int zest_render_fused_set_passes(int shape) {
     return 0;
 }
 
+// Pass shape.  Dense: the blocks of all rays in order, kFusedWaves per pass, block records to the
+// workspace and a second tiny launch chains them.  Ray-aligned: a pass holds kFusedWaves / bpr whole
+// rays and finishes them itself (no record traffic, no second launch); waves beyond that idle.
+// Aligned is taken when it costs no extra round of passes on a device of `cus` compute units (always
+// when bpr divides kFusedWaves: S <= 32, 64, 128, 256 for 32-sample blocks).
+extern "C" int zest_render_fused_pass_shape(int R, int S, int precision, int cus, int *rays_per_pass, int *n_pass) {
+    ZEST_CHECK_ARG(R >= 0 && S >= 1 && zest::prec_is_engine(precision) && rays_per_pass && n_pass,
+                   "zest_render_fused_pass_shape: bad argument");
+    if (cus <= 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            cus = 256;
+    }
+    const int bs = 16 * zest::fused_cb(precision), bpr = (S + bs - 1) / bs;
+    const int W = zest::kFusedWaves;
+    const int dense_pass = zest_div_up((long long)R * bpr, W);
+    const int rpp = bpr <= W ? W / bpr : 0;
+    const int aligned_pass = rpp ? zest_div_up(R, rpp) : 0;
+    int take = (rpp && zest_div_up(aligned_pass, cus) <= zest_div_up(dense_pass, cus)) ? rpp : 0;
+    if (g_pass_shape == 1) take = 0;            // zest_render_fused_set_passes: dense
+    if (g_pass_shape == 2) take = rpp;          // ray-aligned wherever a ray fits a pass
+    *rays_per_pass = take, *n_pass = take ? aligned_pass : dense_pass;
+    return 0;
+}
+
 extern "C" size_t zest_render_fused_workspace(int R, int S) {
     if (R <= 0 || S <= 0) return 16 + kStampBytes;
     // one record per block of a ray; the smallest block (split-fp16 operands) is 16 samples
@@ -119,19 +145,8 @@ extern "C" int zest_render_fused_fwd(const float *ndc, const float *pts, const f
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         cus = 256;
-    // Pass shape.  Dense: the blocks of all rays in order, kFusedWaves per pass, block records to
-    // the workspace and a second tiny launch chains them.  Ray-aligned: a pass holds
-    // kFusedWaves / bpr whole rays and finishes them itself (no record traffic, no second launch);
-    // waves beyond that idle.  Aligned is taken when it costs no extra round of passes on this
-    // device (always when bpr divides kFusedWaves: S <= 32, 64, 128, 256 for 32-sample blocks).
-    const int W = zest::kFusedWaves;
-    const int dense_pass = zest_div_up((long long)R * a.bpr, W);
-    const int rpp = a.bpr <= W ? W / a.bpr : 0;
-    const int aligned_pass = rpp ? zest_div_up(R, rpp) : 0;
-    a.rays_per_pass = (rpp && zest_div_up(aligned_pass, cus) <= zest_div_up(dense_pass, cus)) ? rpp : 0;
-    if (g_pass_shape == 1) a.rays_per_pass = 0;            // zest_render_fused_set_passes: dense
-    if (g_pass_shape == 2) a.rays_per_pass = rpp;          // ray-aligned wherever a ray fits a pass
-    const int n_pass = a.rays_per_pass ? aligned_pass : dense_pass;
+    int n_pass = 0;
+    zest_render_fused_pass_shape(R, S, precision, cus, &a.rays_per_pass, &n_pass);
     const int blocks = n_pass < cus ? n_pass : cus;                 // one workgroup per CU (128 KiB ring)
     hipStream_t st = (hipStream_t)stream;
     const int key = (dyn ? 100 : 0) + nts * 10 + ntd;

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ZEST_ABI_VERSION 2
+#define ZEST_ABI_VERSION 3
 
 /* arithmetic of the MLP contraction */
 #define ZEST_PREC_F32  0   /* v_mfma_f32_32x32x2_f32: exact fp32 products, parity mode */
@@ -41,8 +41,11 @@ extern "C" {
 #define ZEST_HEAD_BLEND   1  /* static net with scene flow: + sigmoid(w_linear)   -> 5   */
 #define ZEST_HEAD_DYNAMIC 2  /* dynamic net: + tanh(sf_linear)(6) sigmoid(prob)(2) -> 12 */
 
-/* Shape of one width-256, depth-8, skip-at-4 NeRF MLP
- * (reference networks.py:73-132 `Renderer`, :223-265 `Renderer_linear`). */
+/* Shape of one NeRF MLP (reference networks.py:73-132 `Renderer`, :223-265 `Renderer_linear`).
+ * depth / width / skip_mask all zero = the shape every shipped config uses (D=8, W=256, skips=[4]),
+ * the only one the MFMA engine (bf16 / fp16 precisions, the fused renderer, the train16 path) covers;
+ * other shapes (reference opt.py:54-57 --netdepth / --netwidth, networks.py:93-100) run on the fp32
+ * kernel (zest_mlp_fwd with ZEST_PREC_F32) and the fp32 training path (zest_mlp_train_*). */
 typedef struct zest_mlp_desc {
     int32_t in_ch_pts;    /* encoded point width: 63 (xyz, L=10) or 84 (xyzt)            */
     int32_t in_ch_feat;   /* F = 8 + 4V per-sample feature width (ignored if !use_feat)   */
@@ -52,19 +55,22 @@ typedef struct zest_mlp_desc {
                           /*     relu(alpha), sigmoid(rgb); 3 = the 'v2' trunk with raw   */
                           /*     outputs (Renderer_linear.forward_alpha; zest_mlp_fwd only) */
     int32_t head;         /* ZEST_HEAD_*                                                   */
+    int32_t depth;        /* D: trunk layers, 2..8 (0 with width = skip_mask = 0: the default shape) */
+    int32_t width;        /* W: trunk width, 64 | 128 | 192 | 256                             */
+    int32_t skip_mask;    /* bit i set: layer i+1 takes [pts | h] (reference `skips` holds i)  */
 } zest_mlp_desc;
 
 /* Parameter order for zest_mlp_pack: weight then bias of each nn.Linear, [out,in]
  * row-major fp32 exactly as in the reference state dict. */
 enum {
-    ZEST_P_PTS0 = 0,          /* pts_linears.0 .. pts_linears.7 -> 0..7 */
-    ZEST_P_PTS_BIAS = 8,      /* pts_bias        [256, F]              */
-    ZEST_P_VIEWS = 9,         /* views_linears.0 [128, 256+27]         */
-    ZEST_P_FEATURE = 10,      /* feature_linear  [256, 256]            */
-    ZEST_P_ALPHA = 11,        /* alpha_linear    [1, 256]              */
-    ZEST_P_RGB = 12,          /* rgb_linear      [3, 128]              */
-    ZEST_P_HEAD0 = 13,        /* w_linear [1,256]  | sf_linear [6,256] */
-    ZEST_P_HEAD1 = 14,        /* (unused)          | prob_linear [2,256] */
+    ZEST_P_PTS0 = 0,          /* pts_linears.0 .. pts_linears.(D-1) -> 0..D-1 */
+    ZEST_P_PTS_BIAS = 8,      /* pts_bias        [W, F]                */
+    ZEST_P_VIEWS = 9,         /* views_linears.0 [W/2, W+27]           */
+    ZEST_P_FEATURE = 10,      /* feature_linear  [W, W]                */
+    ZEST_P_ALPHA = 11,        /* alpha_linear    [1, W]                */
+    ZEST_P_RGB = 12,          /* rgb_linear      [3, W/2]              */
+    ZEST_P_HEAD0 = 13,        /* w_linear [1,W]    | sf_linear [6,W]   */
+    ZEST_P_HEAD1 = 14,        /* (unused)          | prob_linear [2,W] */
     ZEST_P_COUNT = 15
 };
 

@@ -89,17 +89,29 @@ MLP_VARIANTS = {
     "dynamic_mvs24": (PE_XYZT, 24, True, False, True, "v0"),
     "dynamic_nomvs": (PE_XYZT, 24, True, False, False, "v0"),
     "v2_mvs20": (PE_PTS, 20, False, True, True, "v2"),
+    # other depths / widths / skips (reference networks.py:93-100, opt.py:54-57): trailing (D, W, skips)
+    "d4w128_static_mvs20": (PE_PTS, 20, False, True, True, "v0", 4, 128, (1,)),
+    "d6w64_dynamic_mvs24": (PE_XYZT, 24, True, False, True, "v0", 6, 64, (0, 3)),
+    "d3w192_static_sf_nomvs": (PE_PTS, 20, True, True, False, "v0", 3, 192, ()),
+    "d5w128_v2_mvs20": (PE_PTS, 20, False, True, True, "v2", 5, 128, (2,)),
 }
 
 
+def mlp_shape(variant):
+    v = MLP_VARIANTS[variant]
+    return (v[6], v[7], tuple(v[8])) if len(v) > 6 else (8, 256, (4,))
+
+
 def mlp_inputs(seed, variant, M=64):
-    P, Fd, sf, st, mvs, nt = MLP_VARIANTS[variant]
-    lay = zs.mlp_layout(P, PE_DIR, Fd, sf and nt == "v0", st, mvs)
+    P, Fd, sf, st, mvs, nt = MLP_VARIANTS[variant][:6]
+    D, W, skips = mlp_shape(variant)
+    lay = zs.mlp_layout(P, PE_DIR, Fd, sf and nt == "v0", st, mvs, D=D, W=W, skips=skips)
     state = zs.fill_mlp_state(lay, seed)
     g = zs.rng(seed + 1000)
     in_ch = P + (Fd if (mvs or nt == "v2") else 0) + PE_DIR
     x = g.uniform(-1, 1, size=(1, M, in_ch)).astype(np.float32)
-    return dict(state=state, x=x, P=P, Fd=Fd, sceneflow=sf, static=st, use_mvs=mvs, net_type=nt)
+    return dict(state=state, x=x, P=P, Fd=Fd, sceneflow=sf, static=st, use_mvs=mvs, net_type=nt,
+                D=D, W=W, skips=skips)
 
 
 # --------------------------------------------------------------- loss-side cases
@@ -142,17 +154,19 @@ def cost_inputs(seed, V=3, H=18, W=24, D=6, pad=2, spread=0.35):
 
 # --------------------------------------------------------------- rendering cases
 def render_inputs(seed, R=32, S=16, V=3, use_mvs=True, scene_flow=False, use_mvs_dy=True,
-                  lively=True, time_dim=0):
+                  lively=True, time_dim=0, static_shape=None):
     """Small scene (24x32 images, 8x10x12 volume) + seeded MLP weights.  time_dim > 0: the static net
     takes that many time-code channels after the encoded point (Neural3D video mode, reference
-    train.py:91-113, renderer.py:269-273) and the scene carries one latent code `time_codes` [1,T]."""
+    train.py:91-113, renderer.py:269-273) and the scene carries one latent code `time_codes` [1,T].
+    static_shape: (D, W, skips) of the static net when not the shipped 8 / 256 / (4,)."""
     sc = zs.make_scene(seed, R, S, H=24, W=32, V=V, V_dy=4, pad=2, vol_depth=8, focal=30.0,
                        static_volume=use_mvs, dynamic=scene_flow)
     feat_dim = 8 + 4 * V
-    lay_s = zs.mlp_layout(PE_PTS + time_dim, PE_DIR, feat_dim, scene_flow, True, use_mvs)
+    D, W, skips = static_shape or (8, 256, (4,))
+    lay_s = zs.mlp_layout(PE_PTS + time_dim, PE_DIR, feat_dim, scene_flow, True, use_mvs, D=D, W=W, skips=skips)
     sc["state_static"] = zs.fill_mlp_state(lay_s, seed + 1, lively=lively)
     sc.update(feat_dim=feat_dim, feat_dim_dy=24, use_mvs=use_mvs, use_mvs_dy=use_mvs_dy,
-              scene_flow=scene_flow, time_dim=time_dim)
+              scene_flow=scene_flow, time_dim=time_dim, static_shape=(D, W, tuple(skips)))
     if time_dim:
         sc["time_codes"] = zs.rng(seed + 4).standard_normal((1, time_dim)).astype(np.float32)
     if scene_flow:
@@ -220,6 +234,9 @@ CASES = {
     "grad_static": dict(kind="render_grad", seed=42, use_mvs=True, white_bkgd=True),
     "render_static_timecodes": dict(kind="render", seed=43, use_mvs=True, time_dim=8),
     "grad_static_timecodes": dict(kind="render_grad", seed=44, use_mvs=True, time_dim=8),
+    # static net of another depth / width / skips (reference opt.py:54-57), with time codes through both skip layers
+    "render_static_d5w128": dict(kind="render", seed=45, use_mvs=True, time_dim=4, static_shape=(5, 128, (1, 3))),
+    "grad_static_d5w128": dict(kind="render_grad", seed=46, use_mvs=True, time_dim=4, static_shape=(5, 128, (1, 3))),
 }
 
 REF_FRAME_IDX, NUM_FRAMES = 0.1, 24
@@ -269,7 +286,8 @@ def build(case):
     if k in ("render", "render_grad"):
         return render_inputs(c["seed"], use_mvs=c.get("use_mvs", True),
                              scene_flow=c.get("scene_flow", False),
-                             use_mvs_dy=c.get("use_mvs_dy", True), time_dim=c.get("time_dim", 0))
+                             use_mvs_dy=c.get("use_mvs_dy", True), time_dim=c.get("time_dim", 0),
+                             static_shape=c.get("static_shape"))
     raise KeyError(k)
 
 

@@ -21,15 +21,16 @@ def state_t(state, dtype=torch.float32):
     return {k: T(v, dtype) for k, v in state.items()}
 
 
-def spec_of(P, Fd, sceneflow, static, use_mvs, net_type="v0"):
+def spec_of(P, Fd, sceneflow, static, use_mvs, net_type="v0", D=8, W=256, skips=(4,)):
     return zo.MlpSpec(P, gc.PE_DIR, Fd, sceneflow=sceneflow, static=static, use_mvs=use_mvs,
-                      net_type=net_type)
+                      net_type=net_type, D=D, W=W, skips=skips)
 
 
 def render_nets(sc, dtype=torch.float32):
     sf = sc["scene_flow"]
     ns = zo.Net(state_t(sc["state_static"], dtype),
-                spec_of(gc.PE_PTS + sc.get("time_dim", 0), sc["feat_dim"], sf, True, sc["use_mvs"]))
+                spec_of(gc.PE_PTS + sc.get("time_dim", 0), sc["feat_dim"], sf, True, sc["use_mvs"], "v0",
+                        *sc.get("static_shape", (8, 256, (4,)))))
     nd = None
     if sf:
         nd = zo.Net(state_t(sc["state_dynamic"], dtype),
@@ -112,7 +113,7 @@ def run(case, dtype=torch.float32, explicit=True):
                                             explicit)
         elif k == "mlp":
             spec = spec_of(inp["P"], inp["Fd"], inp["sceneflow"], inp["static"], inp["use_mvs"],
-                           inp["net_type"])
+                           inp["net_type"], inp["D"], inp["W"], inp["skips"])
             out["y"] = zo.mlp_forward(state_t(inp["state"], dtype), T(inp["x"], dtype)[0], spec)
             if inp["use_mvs"] or inp["net_type"] == "v2":
                 out["alpha_only"] = zo.mlp_forward_alpha(state_t(inp["state"], dtype),

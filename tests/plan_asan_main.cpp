@@ -30,6 +30,32 @@ int main() {
                                     if (raw_p - hdr != 2 * (raw_q - hdr) || lo != raw_q - hdr || p.parts != 2) return 3;
                                 }
                             }
-    std::printf("plans built: %d\n", n);
+    // other depths / widths / skips: fp32 (ORDER_NATURAL) plans only; the engine order must refuse them
+    int n_shapes = 0;
+    for (int depth = 2; depth <= 8; depth++)
+        for (int width : {64, 128, 192, 256})
+            for (int mask = 0; mask < (1 << (depth - 1)); mask += (depth > 5 ? 5 : 1))
+                for (int use_feat = 0; use_feat < 2; use_feat++) {
+                    zest_mlp_desc d{};
+                    d.in_ch_pts = 63, d.in_ch_feat = 20, d.in_ch_views = 27, d.use_feat = use_feat, d.head = use_feat ? 2 : 0;
+                    d.depth = depth, d.width = width, d.skip_mask = mask;
+                    zest::MlpPlan p;
+                    const char *err = nullptr;
+                    if (!zest::build_plan(d, ZEST_PREC_F32, zest::ORDER_NATURAL, &p, &err, true)) return 4;
+                    if (p.n_ops != depth + 4) return 5;
+                    const bool is_default = depth == 8 && width == 256 && mask == 16;
+                    if (zest::build_plan(d, ZEST_PREC_BF16, zest::ORDER_ACC, &p, &err, false) != is_default) return 6;
+                    n_shapes++;
+                }
+    {
+        zest_mlp_desc d{};
+        d.in_ch_pts = 63, d.in_ch_views = 27, d.depth = 4, d.width = 128, d.skip_mask = 1 << 3;   // no layer 4 to widen
+        zest::MlpPlan p;
+        const char *err = nullptr;
+        if (zest::build_plan(d, ZEST_PREC_F32, zest::ORDER_NATURAL, &p, &err, false)) return 7;
+        d.skip_mask = 0, d.width = 100;
+        if (zest::build_plan(d, ZEST_PREC_F32, zest::ORDER_NATURAL, &p, &err, false)) return 8;
+    }
+    std::printf("plans built: %d\nshape plans built: %d\n", n, n_shapes);
     return n > 0 ? 0 : 1;
 }

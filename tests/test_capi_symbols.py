@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(zest_hip.LIB_PATH)
     for name in _declared():
         assert hasattr(lib, name), name
-    assert lib.zest_abi_version() == 2
+    assert lib.zest_abi_version() == 3
 
 
 def test_missing_library_is_an_error(monkeypatch):

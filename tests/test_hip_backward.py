@@ -11,7 +11,7 @@ import torch
 import golden_cases as gc
 import oracle_run
 from oracle import zest_oracle as zo
-from test_hip_ops import G, _mlp_setup
+from test_hip_ops import G, _mlp_setup, _mlp_module
 from test_hip_render import build_nets
 
 pytestmark = pytest.mark.gpu
@@ -66,13 +66,8 @@ def test_blend_backward(hip):
 
 @pytest.mark.parametrize("case", [c for c in gc.CASES if gc.CASES[c]["kind"] == "mlp"])
 def test_mlp_train_forward_backward(hip, case):
-    import zest_networks as networks
     zh, inp, desc, _ = _mlp_setup(case)
-    net = networks.MVSNeRF(D=8, W=256, input_ch_pts=inp["P"], input_ch_views=27, input_ch_feat=inp["Fd"],
-                           net_type=inp["net_type"], sceneflow=inp["sceneflow"], static=inp["static"],
-                           use_mvs=inp["use_mvs"])
-    net.load_state_dict({k: torch.from_numpy(v) for k, v in inp["state"].items()})
-    net = net.cuda()
+    net = _mlp_module(inp)
     x = G(inp["x"])[0].requires_grad_(True)
     y = net(x)                                     # grad mode -> training path
     gold = gc.load_golden(case)["y"]
@@ -81,7 +76,8 @@ def test_mlp_train_forward_backward(hip, case):
     Wt = gc.zs.rng(5).standard_normal(gold.shape).astype(np.float32)
     (G(Wt) * y).sum().backward()
     # oracle
-    spec = oracle_run.spec_of(inp["P"], inp["Fd"], inp["sceneflow"], inp["static"], inp["use_mvs"], inp["net_type"])
+    spec = oracle_run.spec_of(inp["P"], inp["Fd"], inp["sceneflow"], inp["static"], inp["use_mvs"], inp["net_type"],
+                              inp["D"], inp["W"], inp["skips"])
     st = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in inp["state"].items()}
     xo = torch.from_numpy(inp["x"])[0].clone().requires_grad_(True)
     (torch.from_numpy(Wt) * zo.mlp_forward(st, xo, spec)).sum().backward()
@@ -118,7 +114,7 @@ def test_encode_backward(hip):
     gclose(vol.grad[0], vol_o.grad.numpy(), "g_volume")
 
 
-@pytest.mark.parametrize("case", ["grad_zest_5f", "grad_static", "grad_static_timecodes"])
+@pytest.mark.parametrize("case", ["grad_zest_5f", "grad_static", "grad_static_timecodes", "grad_static_d5w128"])
 def test_rendering_training_gradients(hip, case):
     """Whole train-mode rendering(): loss over every differentiable output, gradients of both
     MLPs' parameters, both encoding volumes and (Neural3D mode) the frame's time code."""
@@ -152,7 +148,7 @@ def test_rendering_training_gradients(hip, case):
     want_loss, want32 = oracle_run.oracle_render_grads(case)
     _, want = oracle_run.oracle_render_grads(case, torch.float64)
     gold = gc.load_golden(case)
-    assert abs(float(loss) - want_loss) <= 2e-3 * max(1.0, abs(want_loss))
+    assert abs(float(loss.detach()) - want_loss) <= 2e-3 * max(1.0, abs(want_loss))
     got = {}
     for tag, net in (("static", ns), ("dynamic", nd)):
         if net is not None:

@@ -115,16 +115,33 @@ def _mlp_setup(case):
     if inp["sceneflow"] and inp["net_type"] == "v0":
         head = zest_hip.HEAD_BLEND if inp["static"] else zest_hip.HEAD_DYNAMIC
     use_feat = inp["use_mvs"] or inp["net_type"] == "v2"
+    shape = ()
+    if (inp["D"], inp["W"], tuple(inp["skips"])) != (8, 256, (4,)):
+        shape = (inp["D"], inp["W"], sum(1 << i for i in inp["skips"]))
     desc = zest_hip.MlpDesc(inp["P"], inp["Fd"], gc.PE_DIR, int(use_feat),
-                            2 if inp["net_type"] == "v2" else 0, head)
+                            2 if inp["net_type"] == "v2" else 0, head, *shape)
     state = {k: G(v) for k, v in inp["state"].items()}
     return zest_hip, inp, desc, zest_hip.param_table(state, desc)
 
 
-MLP_CASES = [c for c in gc.CASES if gc.CASES[c]["kind"] == "mlp"]
+def _mlp_module(inp):
+    """zest_networks.MVSNeRF of an MLP case (any depth / width / skips) with the case's weights, on the GPU."""
+    import zest_networks as networks
+    net = networks.MVSNeRF(D=inp["D"], W=inp["W"], skips=list(inp["skips"]), input_ch_pts=inp["P"],
+                           input_ch_views=gc.PE_DIR, input_ch_feat=inp["Fd"], net_type=inp["net_type"],
+                           sceneflow=inp["sceneflow"], static=inp["static"], use_mvs=inp["use_mvs"])
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in inp["state"].items()})
+    return net.cuda()
 
 
-@pytest.mark.parametrize("case", MLP_CASES)
+# every MLP case runs in the fp32 kernel and the fp32 training path; the MFMA engine (bf16 / fp16 / split
+# fp16) is written for the shipped shape D=8, W=256, skips=[4]
+ALL_MLP_CASES = [c for c in gc.CASES if gc.CASES[c]["kind"] == "mlp"]
+SHAPE_MLP_CASES = [c for c in ALL_MLP_CASES if gc.mlp_shape(gc.CASES[c]["variant"]) != (8, 256, (4,))]
+MLP_CASES = [c for c in ALL_MLP_CASES if c not in SHAPE_MLP_CASES]
+
+
+@pytest.mark.parametrize("case", ALL_MLP_CASES)
 def test_mlp_f32(hip, case):
     zh, inp, desc, tab = _mlp_setup(case)
     packed = zh.mlp_pack(desc, zh.PREC_F32, tab)
@@ -140,6 +157,26 @@ def test_mlp_bf16(hip, case):
     gold = gc.load_golden(case)["y"]
     scale = np.abs(gold).max()
     close(y, gold, atol=3e-2 * scale, rtol=3e-2, name=case)
+
+
+@pytest.mark.parametrize("case", SHAPE_MLP_CASES)
+def test_mlp_other_shapes_refuse_the_engine_and_run_fp32_from_the_module(hip, case, monkeypatch):
+    """Depths / widths / skips other than 8 / 256 / [4] (reference networks.py:93-100): the engine precisions
+    refuse them at the C ABI with a message, and the module routes every mode to the fp32 kernel."""
+    zh, inp, desc, tab = _mlp_setup(case)
+    for prec in (zh.PREC_BF16, zh.PREC_F16, zh.PREC_F16X3):
+        with pytest.raises(RuntimeError, match="depth 8 / width 256"):
+            zh.mlp_pack(desc, prec, tab)
+    gold = gc.load_golden(case)
+    for mode in ("f32", "bf16", "f16"):
+        monkeypatch.setenv("ZEST_PRECISION", mode)
+        net = _mlp_module(inp)
+        with torch.no_grad():
+            y = net(G(inp["x"]))
+            close(y[0], gold["y"], name="%s/%s" % (case, mode))
+            if "alpha_only" in gold:
+                a = net.forward_alpha(G(inp["x"])[..., :inp["P"] + inp["Fd"]])
+                close(a[0], gold["alpha_only"], name="%s/%s/forward_alpha" % (case, mode))
 
 
 def test_mlp_ragged_batch(hip):
@@ -210,11 +247,7 @@ def test_forward_alpha_matches_reference(hip, case, exact, monkeypatch):
     import zest_networks as networks
     monkeypatch.setenv("ZEST_FP32_EXACT", "1" if exact else "0")
     inp, gold = gc.build(case), gc.load_golden(case)
-    net = networks.MVSNeRF(D=8, W=256, input_ch_pts=inp["P"], input_ch_views=gc.PE_DIR, input_ch_feat=inp["Fd"],
-                           net_type=inp["net_type"], sceneflow=inp["sceneflow"], static=inp["static"],
-                           use_mvs=inp["use_mvs"])
-    net.load_state_dict({k: torch.from_numpy(v) for k, v in inp["state"].items()})
-    net = net.cuda()
+    net = _mlp_module(inp)
     with torch.no_grad():
         a = net.forward_alpha(G(inp["x"])[..., :inp["P"] + inp["Fd"]])
         y = net(G(inp["x"]))                        # the full forward still packs and runs its own variant

@@ -23,8 +23,9 @@ CHAIN2 = ("raw_pts_pp", "rgb_map_pp_dy")
 def build_nets(sc, net_type="v0"):
     import zest_networks as networks
     sf = sc["scene_flow"]
-    ns = networks.MVSNeRF(D=8, W=256, input_ch_pts=gc.PE_PTS + sc.get("time_dim", 0), output_ch=4,
-                          input_ch_views=gc.PE_DIR, input_ch_feat=sc["feat_dim"], skips=[4], net_type=net_type,
+    D, W, skips = sc.get("static_shape", (8, 256, (4,)))
+    ns = networks.MVSNeRF(D=D, W=W, input_ch_pts=gc.PE_PTS + sc.get("time_dim", 0), output_ch=4,
+                          input_ch_views=gc.PE_DIR, input_ch_feat=sc["feat_dim"], skips=list(skips), net_type=net_type,
                           sceneflow=sf, static=True, use_mvs=sc["use_mvs"])
     ns.load_state_dict({k: torch.from_numpy(v) for k, v in sc["state_static"].items()})
     nd = None

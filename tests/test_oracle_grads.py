@@ -8,7 +8,7 @@ import golden_cases as gc
 import oracle_run
 
 
-@pytest.mark.parametrize("case", ["grad_zest_5f", "grad_static"])
+@pytest.mark.parametrize("case", ["grad_zest_5f", "grad_static", "grad_static_timecodes", "grad_static_d5w128"])
 def test_oracle_gradients_match_reference(case):
     gold = gc.load_golden(case)
     loss, grads = oracle_run.oracle_render_grads(case)

@@ -23,4 +23,5 @@ def test_plan_builder_is_clean_under_asan_ubsan(tmp_path):
     assert build.returncode == 0, build.stderr[-2000:]
     run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, (run.stdout + run.stderr)[-2000:]
-    assert "plans built:" in run.stdout and int(run.stdout.split(":")[1]) > 100
+    assert "plans built:" in run.stdout and int(run.stdout.split(":")[1].split()[0]) > 100
+    assert int(run.stdout.split("shape plans built:")[1]) > 100

@@ -66,9 +66,9 @@ def T(a):
     return torch.from_numpy(np.ascontiguousarray(a))
 
 
-def ref_net(ref, state, P, Fd, sceneflow, static, use_mvs, net_type="v0"):
-    net = ref.networks.MVSNeRF(D=8, W=256, input_ch_pts=P, output_ch=4, input_ch_views=gc.PE_DIR,
-                               input_ch_feat=Fd, skips=[4], net_type=net_type,
+def ref_net(ref, state, P, Fd, sceneflow, static, use_mvs, net_type="v0", D=8, W=256, skips=(4,)):
+    net = ref.networks.MVSNeRF(D=D, W=W, input_ch_pts=P, output_ch=4, input_ch_views=gc.PE_DIR,
+                               input_ch_feat=Fd, skips=list(skips), net_type=net_type,
                                sceneflow=sceneflow, static=static, use_mvs=use_mvs)
     missing = net.load_state_dict({k: T(v) for k, v in state.items()}, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
@@ -109,7 +109,7 @@ def run_case(ref, name):
                                                          with_mask=True).numpy()[0]
         elif k == "mlp":
             net = ref_net(ref, inp["state"], inp["P"], inp["Fd"], inp["sceneflow"], inp["static"],
-                          inp["use_mvs"], inp["net_type"])
+                          inp["use_mvs"], inp["net_type"], inp["D"], inp["W"], inp["skips"])
             out["y"] = net(T(inp["x"])).numpy()[0]
             if inp["use_mvs"] or inp["net_type"] == "v2":          # x carries the feature columns forward_alpha reads
                 out["alpha_only"] = net.forward_alpha(T(inp["x"])[..., :inp["P"] + inp["Fd"]]).numpy()[0]
@@ -222,7 +222,8 @@ def run_render(ref, c, sc, want_grad=False):
     e_pts = ref.networks.Embedding(3, 10)
     e_xyzt = ref.networks.Embedding(4, 10)
     e_dir = ref.networks.Embedding(3, 4)
-    net_s = ref_net(ref, sc["state_static"], gc.PE_PTS + sc.get("time_dim", 0), sc["feat_dim"], sf, True, sc["use_mvs"])
+    net_s = ref_net(ref, sc["state_static"], gc.PE_PTS + sc.get("time_dim", 0), sc["feat_dim"], sf, True, sc["use_mvs"],
+                    "v0", *sc["static_shape"])
     tc = T(sc["time_codes"]).requires_grad_(want_grad) if sc.get("time_dim", 0) else None
     net_d = None
     if sf:

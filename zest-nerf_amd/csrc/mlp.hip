@@ -24,7 +24,7 @@ struct DevPlan {
 };
 
 std::mutex g_mu;
-std::map<std::tuple<int, int, int, int, int, int, int, int>, DevPlan *> g_plans;
+std::map<std::tuple<int, int, int, int, int, int, int, int, int, int, int>, DevPlan *> g_plans;
 
 constexpr int kOrderBwd = 99;       // key of the training path's backward-data stream (bf16, build_bwd_plan)
 
@@ -32,7 +32,7 @@ constexpr int kOrderBwd = 99;       // key of the training path's backward-data 
 DevPlan *get_plan(const zest_mlp_desc &d, int precision, int order, bool need_tables) {
     std::lock_guard<std::mutex> lk(g_mu);
     auto key = std::make_tuple(d.in_ch_pts, d.use_feat ? d.in_ch_feat : 0, d.in_ch_views,
-                               d.use_feat, d.net_type, d.head, precision, order);
+                               d.use_feat, d.net_type, d.head, precision, order, d.depth, d.width, d.skip_mask);
     auto it = g_plans.find(key);
     DevPlan *dp = it == g_plans.end() ? nullptr : it->second;
     if (!dp) {
@@ -121,6 +121,7 @@ struct F32Op {
 };
 struct F32Prog {
     F32Op op[zest::kNumOps];
+    int n_ops, W;              // depth + 4 ops; trunk width
     int P, F, Vw, C_in, C_out, nt_feat, net_v2, act_out, head;     // net_v2: additive modulation; act_out: sigmoid(rgb), relu(alpha)
     int rows_pts, rows_feat;   // padded row counts of the input buffers
 };
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(F32Prog pr, const float
     float *b_pts = smem;                                   // [rows_pts][32]
     float *b_feat = b_pts + pr.rows_pts * 32;              // [rows_feat][32]
     float *b_views = b_feat + pr.rows_feat * 32;           // [32][32]
-    float *b_h[2] = {b_views + 32 * 32, b_views + 32 * 32 + zest::kW * 32};
+    float *b_h[2] = {b_views + 32 * 32, b_views + 32 * 32 + pr.W * 32};
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, half = lane >> 5;
     const int n_in_rows = pr.rows_pts + pr.rows_feat + 32;
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(F32Prog pr, const float
         }
         __syncthreads();
 #pragma unroll 1
-        for (int o = 0; o < zest::kNumOps; o++) {
+        for (int o = 0; o < pr.n_ops; o++) {
             const F32Op op = pr.op[o];
             for (int jb = wave; jb < op.njb; jb += 4) {
                 const float4 *tp = tiles + ((size_t)op.tile_base + (size_t)jb * op.tiles_per_jb) * 64 + lane;
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(F32Prog pr, const float
                         b_h[op.dst][row * 32 + col] = v;
                     } else if (col < nvalid) {
                         float *orow = out + (size_t)(m0 + col) * pr.C_out;
-                        if (o == 11) {                       // rgb tile
+                        if (o == pr.n_ops - 1) {             // rgb tile
                             if (row < 3) orow[row] = pr.act_out ? zest_sigmoid(v) : v;
                         } else if (row == 0) {               // head tile: alpha
                             orow[3] = pr.act_out ? fmaxf(v, 0.0f) : v;
@@ -219,17 +220,19 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(F32Prog pr, const float
 
 F32Prog make_f32_prog(const MlpPlan &p) {
     F32Prog pr = {};
-    // trunk ping-pong: L0 -> A(0), then alternate; L7 lands in B(1); head reads B; feature
-    // B -> A; views A -> B; rgb reads B
-    static const int src_h[zest::kNumOps] = {0, 0, 1, 0, 1, 0, 1, 0, 1, 1, 0, 1};
-    static const int dst[zest::kNumOps] = {0, 1, 0, 1, 0, 1, 0, 1, 2, 0, 1, 2};
-    for (int o = 0; o < zest::kNumOps; o++) {
+    // trunk ping-pong: layer l lands in buffer l & 1, so the trunk output sits in t = (D-1) & 1 (depth 8: B);
+    // the head tile reads t; feature t -> 1-t; view layer 1-t -> t; rgb reads t
+    const int D = p.shape.D, t = (D - 1) & 1;
+    pr.n_ops = p.n_ops, pr.W = p.shape.W;
+    for (int o = 0; o < p.n_ops; o++) {
         const zest::OpPlan &s = p.op[o];
         F32Op &d = pr.op[o];
+        const int src_h = o < D ? (o + 1) & 1 : (o == D + 2 ? 1 - t : t);
+        const int dst = o < D ? o & 1 : (o == D + 1 ? 1 - t : (o == D + 2 ? t : 2));
         d.njb = s.njb, d.nseg = s.nseg, d.kind0 = s.seg[0].kind, d.nt0 = s.seg[0].ntiles;
         d.kind1 = s.seg[1].kind, d.nt1 = s.seg[1].ntiles, d.mod = s.mod, d.relu = s.relu;
         d.tile_base = s.tile_base, d.tiles_per_jb = s.tiles_per_jb, d.bias_block = s.bias_block;
-        d.src_h = src_h[o], d.dst = dst[o];
+        d.src_h = src_h, d.dst = dst;
     }
     pr.P = p.desc.in_ch_pts, pr.F = p.desc.use_feat ? p.desc.in_ch_feat : 0, pr.Vw = p.desc.in_ch_views;
     pr.C_in = pr.P + pr.F + pr.Vw;
@@ -282,7 +285,7 @@ extern "C" int zest_mlp_pack(const zest_mlp_desc *desc, int precision, const flo
     for (int i = 0; i < 2 * ZEST_P_COUNT; i++) pt.p[i] = params[i];
     // every parameter the gather tables reference must be present
     bool need[ZEST_P_COUNT] = {};
-    for (int i = 0; i < 8; i++) need[i] = true;
+    for (int i = 0; i < p.shape.D; i++) need[i] = true;
     need[ZEST_P_PTS_BIAS] = desc->use_feat != 0;
     need[ZEST_P_VIEWS] = need[ZEST_P_FEATURE] = need[ZEST_P_ALPHA] = need[ZEST_P_RGB] = true;
     need[ZEST_P_HEAD0] = desc->head != ZEST_HEAD_NONE;
@@ -324,7 +327,7 @@ extern "C" int zest_mlp_fwd(const zest_mlp_desc *desc, int precision, const void
     const void *tiles = (const char *)packed + p.bias_bytes;
     if (precision == ZEST_PREC_F32) {
         const F32Prog pr = make_f32_prog(p);
-        const size_t lds = (size_t)(pr.rows_pts + pr.rows_feat + 32 + 2 * zest::kW) * 32 * sizeof(float);
+        const size_t lds = (size_t)(pr.rows_pts + pr.rows_feat + 32 + 2 * pr.W) * 32 * sizeof(float);
         const int blocks = zest_div_up(M, kF32Samples);
         hipLaunchKernelGGL(mlp_f32_kernel, dim3(blocks < 4096 ? blocks : 4096), dim3(256), lds,
                            (hipStream_t)stream, pr, bias, (const float4 *)tiles, x, M, out);

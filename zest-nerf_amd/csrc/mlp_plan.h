@@ -1,12 +1,14 @@
 // Host-side plan of the width-256 NeRF MLP as the MFMA kernels execute it.
 //
-// The network (reference networks.py:150-221) is a fixed sequence of 12 "ops", each a
-// Linear producing NJB row-blocks of 32 output features:
-//   0..7  trunk layers  h = relu((W h + b) (*|+) m),  m = pts_bias(feats) recomputed per tile
-//   8     head tile     rows: alpha, then w | sf(6) prob(2)      (on the trunk output)
-//   9     feature_linear (no activation)
-//   10    views_linears.0 on [feature | PE(dir)], relu
-//   11    rgb_linear
+// The network (reference networks.py:150-221) is a sequence of D + 4 "ops" (12 at the default depth 8),
+// each a Linear producing NJB row-blocks of 32 output features:
+//   0..D-1  trunk layers  h = relu((W h + b) (*|+) m),  m = pts_bias(feats) recomputed per tile
+//   D       head tile     rows: alpha, then w | sf(6) prob(2)      (on the trunk output)
+//   D+1     feature_linear (no activation)
+//   D+2     views_linears.0 on [feature | PE(dir)], relu
+//   D+3     rgb_linear
+// The ORDER_ACC engine and everything below "bf16 training path" are written for D = 8, W = 256,
+// skips = [4] (their op ids 8..11 are literal); other depths / widths / skips exist in ORDER_NATURAL only.
 // Work is done transposed, Y^T = W X^T: samples sit on the MFMA column/lane axis and the
 // output features of a tile in its accumulator registers, so a tile's activations feed the
 // next op's B operand without leaving the lane.
@@ -47,8 +49,8 @@
 
 namespace zest {
 
-constexpr int kW = 256;            // trunk width (every shipped config: netwidth = 256)
-constexpr int kNumOps = 12;
+constexpr int kW = 256;            // default trunk width (every shipped config: netwidth = 256), the engine's only one
+constexpr int kNumOps = 12;        // op slots: depth <= 8
 constexpr int kMaxSeg = 2;
 constexpr int kStreamAlign = 128;  // units (KiB): ring size the bf16 stream is padded to
 
@@ -76,8 +78,19 @@ struct OpPlan {
     int bias_block;          // first bias block (128 B units)
 };
 
+// desc->depth / width / skip_mask resolved (all zero = 8 / 256 / skips [4]) and range-checked
+struct MlpShape {
+    int D, W, skip_mask;
+    bool is_default;
+};
+bool mlp_shape(const zest_mlp_desc &d, MlpShape *s, const char **err);
+// leading dimension (input width) of every ZEST_P_* weight
+void mlp_param_ld(const zest_mlp_desc &d, const MlpShape &s, int *ld);
+
 struct MlpPlan {
     zest_mlp_desc desc;
+    MlpShape shape;
+    int n_ops;                     // shape.D + 4
     int precision, order;
     int spt;                       // slots per tile
     int ns_pts, ns_feat, ns_views; // padded slot counts of the encoder operands

@@ -89,8 +89,15 @@ bool build_plan(const zest_mlp_desc &d, int precision, int order, MlpPlan *P, co
         (d.net_type >= 2 && (d.head != 0 || !d.use_feat)))
         return *err = e_head, false;
 
+    MlpShape sh;
+    if (!mlp_shape(d, &sh, err)) return false;
+    if (order == ORDER_ACC && !sh.is_default)
+        return *err = "the MFMA engine covers depth 8 / width 256 / skips [4]; other shapes run in ZEST_PREC_F32", false;
+    const int D = sh.D, Wd = sh.W;
+
     MlpPlan &p = *P;
-    p.desc = d, p.precision = precision, p.order = order;
+    p.desc = d, p.precision = precision, p.order = order, p.shape = sh;
+    p.n_ops = D + 4;
     p.spt = prec_is_engine(precision) ? 8 : 4;
     p.parts = precision == ZEST_PREC_F16X3 ? 2 : 1;
     const int spt = p.spt, C = d.in_ch_pts == 63 ? 3 : 4, V = d.use_feat ? (F - 8) / 4 : 0;
@@ -113,21 +120,23 @@ bool build_plan(const zest_mlp_desc &d, int precision, int order, MlpPlan *P, co
     }
     const int spu = order == ORDER_ACC ? 16 : spt;          // operand slots / positions per stream unit
     p.nt_pts = p.ns_pts / spu, p.nt_views = p.ns_views / spu, p.nt_feat = p.ns_feat / spu;
-    p.nt_h = order == ORDER_ACC ? 16 : 128 / spt, p.nt_h128 = order == ORDER_ACC ? 8 : 64 / spt;
+    p.nt_h = order == ORDER_ACC ? 16 : Wd / 2 / spt, p.nt_h128 = order == ORDER_ACC ? 8 : Wd / 4 / spt;
 
     // ---- op table ----------------------------------------------------------------------
     p.headers = order == ORDER_ACC ? 1 : 0;
-    int tile = 0, bblk = d.use_feat ? 8 : 0;
-    for (int o = 0; o < kNumOps; o++) {
+    // op ids: 0 .. D-1 trunk, D head tile, D+1 feature_linear, D+2 view layer, D+3 rgb_linear
+    memset(p.op, 0, sizeof(p.op));
+    int tile = 0, bblk = d.use_feat ? Wd / 32 : 0;
+    for (int o = 0; o < p.n_ops; o++) {
         OpPlan &op = p.op[o];
-        memset(&op, 0, sizeof(op));
-        op.njb = 8, op.nseg = 1, op.seg[0] = {SEG_H, p.nt_h};
-        if (o < 8) op.mod = d.use_feat ? 1 : 0, op.relu = 1;
+        op.njb = Wd / 32, op.nseg = 1, op.seg[0] = {SEG_H, p.nt_h};
+        if (o < D) op.mod = d.use_feat ? 1 : 0, op.relu = 1;
         if (o == 0) op.seg[0] = {SEG_PTS, p.nt_pts};
-        if (o == 5) op.nseg = 2, op.seg[0] = {SEG_PTS, p.nt_pts}, op.seg[1] = {SEG_H, p.nt_h};
-        if (o == 8) op.njb = 1;
-        if (o == 10) op.njb = 4, op.relu = 1, op.nseg = 2, op.seg[1] = {SEG_VIEWS, p.nt_views};
-        if (o == 11) op.njb = 1, op.seg[0] = {SEG_H, p.nt_h128};
+        if (o > 0 && o < D && (sh.skip_mask >> (o - 1) & 1))
+            op.nseg = 2, op.seg[0] = {SEG_PTS, p.nt_pts}, op.seg[1] = {SEG_H, p.nt_h};
+        if (o == D) op.njb = 1;
+        if (o == D + 2) op.njb = Wd / 64, op.relu = 1, op.nseg = 2, op.seg[1] = {SEG_VIEWS, p.nt_views};
+        if (o == D + 3) op.njb = 1, op.seg[0] = {SEG_H, p.nt_h128};
         op.tiles_per_jb = (op.mod ? p.nt_feat : 0) * p.parts + p.headers;
         for (int s = 0; s < op.nseg; s++) op.tiles_per_jb += op.seg[s].ntiles * p.parts;
         op.tile_base = tile, op.bias_block = bblk;
@@ -140,8 +149,8 @@ bool build_plan(const zest_mlp_desc &d, int precision, int order, MlpPlan *P, co
 
     if (!with_tables) return true;
     // ---- gather tables -------------------------------------------------------------------
-    const int ld[ZEST_P_COUNT] = {d.in_ch_pts, kW, kW, kW, kW, kW + d.in_ch_pts, kW, kW,
-                                  d.in_ch_feat, kW + d.in_ch_views, kW, kW, kW / 2, kW, kW};
+    int ld[ZEST_P_COUNT];
+    mlp_param_ld(d, sh, ld);
     const uint32_t ZERO = 0xFFFFFFFFu;
     p.tile_src.assign((size_t)tile * 64 * spt, ZERO);
     p.bias_src.assign(p.bias_bytes / 4, ZERO);
@@ -149,10 +158,10 @@ bool build_plan(const zest_mlp_desc &d, int precision, int order, MlpPlan *P, co
     p.unit_part.assign((size_t)tile, 0);
 
     auto row_src = [&](int o, int row) -> RowSrc {
-        if (o < 8) return {ZEST_P_PTS0 + o, row};
-        if (o == 9) return {ZEST_P_FEATURE, row};
-        if (o == 10) return {row < kW / 2 ? ZEST_P_VIEWS : -1, row};
-        if (o == 11) return {row < 3 ? ZEST_P_RGB : -1, row};
+        if (o < D) return {ZEST_P_PTS0 + o, row};
+        if (o == D + 1) return {ZEST_P_FEATURE, row};
+        if (o == D + 2) return {row < Wd / 2 ? ZEST_P_VIEWS : -1, row};
+        if (o == D + 3) return {row < 3 ? ZEST_P_RGB : -1, row};
         // head tile: row 0 alpha, then the extra heads in output order
         if (row == 0) return {ZEST_P_ALPHA, 0};
         if (d.head == ZEST_HEAD_BLEND && row == 1) return {ZEST_P_HEAD0, 0};
@@ -210,8 +219,8 @@ bool build_plan(const zest_mlp_desc &d, int precision, int order, MlpPlan *P, co
         emit_bias_to(p.bias_src, (size_t)block * 32, o, jb, is_mod);
     };
     if (d.use_feat && !p.headers)
-        for (int jb = 0; jb < 8; jb++) emit_bias(jb, 0, jb, true);
-    for (int o = 0; o < kNumOps; o++) {
+        for (int jb = 0; jb < Wd / 32; jb++) emit_bias(jb, 0, jb, true);
+    for (int o = 0; o < p.n_ops; o++) {
         const OpPlan &op = p.op[o];
         int t = op.tile_base;
         for (int jb = 0; jb < op.njb; jb++) {
@@ -227,11 +236,29 @@ bool build_plan(const zest_mlp_desc &d, int precision, int order, MlpPlan *P, co
             for (int s = 0; s < op.nseg; s++) {
                 emit_tiles(t, o, jb, op.seg[s], col0, false);
                 // width of the operand just consumed, in the Linear's own column order
-                col0 += op.seg[s].kind == SEG_PTS ? d.in_ch_pts : kW;
+                col0 += op.seg[s].kind == SEG_PTS ? d.in_ch_pts : Wd;
             }
         }
     }
     return true;
+}
+
+bool mlp_shape(const zest_mlp_desc &d, MlpShape *s, const char **err) {
+    const bool unset = d.depth == 0 && d.width == 0 && d.skip_mask == 0;
+    s->D = unset ? 8 : d.depth, s->W = unset ? kW : d.width, s->skip_mask = unset ? 1 << 4 : d.skip_mask;
+    if (s->D < 2 || s->D > 8) return *err = "depth must be 2 .. 8", false;
+    if (s->W != 64 && s->W != 128 && s->W != 192 && s->W != 256) return *err = "width must be 64, 128, 192 or 256", false;
+    // reference networks.py:93-100: `i in skips` widens layer i+1; an entry >= D-1 has no layer to widen
+    if (s->skip_mask < 0 || (s->skip_mask >> (s->D - 1)) != 0) return *err = "skip_mask names a layer beyond depth", false;
+    s->is_default = s->D == 8 && s->W == kW && s->skip_mask == 1 << 4;
+    return true;
+}
+
+void mlp_param_ld(const zest_mlp_desc &d, const MlpShape &s, int *ld) {
+    for (int l = 0; l < 8; l++)
+        ld[ZEST_P_PTS0 + l] = l == 0 ? d.in_ch_pts : s.W + ((s.skip_mask >> (l - 1) & 1) ? d.in_ch_pts : 0);
+    ld[ZEST_P_PTS_BIAS] = d.in_ch_feat, ld[ZEST_P_VIEWS] = s.W + d.in_ch_views, ld[ZEST_P_FEATURE] = s.W;
+    ld[ZEST_P_ALPHA] = s.W, ld[ZEST_P_RGB] = s.W / 2, ld[ZEST_P_HEAD0] = s.W, ld[ZEST_P_HEAD1] = s.W;
 }
 
 

@@ -1,40 +1,51 @@
-// Training path of the width-256 MLP: fp32 forward that keeps the
+// Training path of the NeRF MLP, any depth / width / skips the desc allows: fp32 forward that keeps the
 // activations backward needs, and the backward itself.  The GEMMs here are plain library
-// shapes ([M x K] . [K x 256] with M = rays x samples), so they go to rocBLAS sgemm (exact
+// shapes ([M x K] . [K x W] with M = rays x samples), so they go to rocBLAS sgemm (exact
 // fp32 products on gfx950: there is no xf32 path); everything between them - bias,
 // multiplicative / additive modulation by pts_bias(feats), ReLU and its mask, the skip
 // concatenation, head activations - is fused into three small HIP kernels.
 //
-// Layout of one sample's saved activations (kSavedPerSample floats), row-major per buffer:
-//   pre[l] = Linear_l(h) + b_l  for the 8 trunk layers, m = pts_bias(feats), the
-//   feature_linear output, and the pre-activation of the view layer.
+// Layout of one sample's saved activations (saved_per_sample floats), row-major per buffer:
+//   pre[l] = Linear_l(h) + b_l  for the D trunk layers, m = pts_bias(feats), the
+//   feature_linear output, and the pre-activation of the view layer (W/2 wide).
 // Replaces the autograd of Renderer.forward / Renderer_linear.forward
 // (reference networks.py:150-221, 283-319).
 #include <rocblas/rocblas.h>
 #include <mutex>
+#include "mlp_plan.h"
 #include "zest_common.cuh"
 
 namespace {
 
-constexpr int W = 256, HW = 128;
-constexpr int kSavedPerSample = 8 * W + W + W + HW;                 // 2688
-constexpr int kWorkPerSample = 2 * W /*act ping-pong*/ + 4 * W /*d_a, d_b, act_re, dm*/ + W /*d_feat*/ +
-                               HW /*d_hv*/ + 16 /*head pre / d*/ + 1 /*ones*/;
+inline int saved_per_sample(int D, int W) { return D * W + W + W + W / 2; }      // 2688 at the default shape
+inline int work_per_sample(int W) {
+    return 2 * W /*act ping-pong*/ + 4 * W /*d_a, d_b, act_re, dm*/ + W /*d_feat*/ + W / 2 /*d_hv*/ +
+           16 /*head pre / d*/ + 1 /*ones*/;
+}
 
 constexpr int kSplitRows = 2048;                       // rows of M per weight-gradient partial product
 constexpr size_t kPartialFloats = (size_t)64 * 256 * 320;   // split-K partials: up to 64 x [256 x 319]
 
 struct Shape {
     int P, F, V, C_in, C_out, head, v2, mod, n_extra;
+    int D, W, HW, skip_mask;
+    bool skip_in(int l) const { return l > 0 && (skip_mask >> (l - 1) & 1); }      // layer l reads [pts | h]
 };
 
-Shape shape_of(const zest_mlp_desc &d) {
-    Shape s;
+bool shape_of(const zest_mlp_desc &d, Shape *out) {
+    Shape &s = *out;
+    zest::MlpShape ms;
+    const char *err = nullptr;
+    if (!zest::mlp_shape(d, &ms, &err)) {
+        zest_set_error("zest_mlp_train: %s", err);
+        return false;
+    }
+    s.D = ms.D, s.W = ms.W, s.HW = ms.W / 2, s.skip_mask = ms.skip_mask;
     s.P = d.in_ch_pts, s.mod = d.use_feat ? 1 : 0, s.F = s.mod ? d.in_ch_feat : 0, s.V = d.in_ch_views;
     s.C_in = s.P + s.F + s.V, s.head = d.head, s.v2 = d.net_type == 2;
     s.n_extra = d.head == ZEST_HEAD_BLEND ? 1 : (d.head == ZEST_HEAD_DYNAMIC ? 8 : 0);
     s.C_out = 4 + s.n_extra;
-    return s;
+    return true;
 }
 
 rocblas_handle g_handle = nullptr;
@@ -226,10 +237,12 @@ struct GradParams {
 }  // namespace
 
 extern "C" size_t zest_mlp_train_saved_floats(const zest_mlp_desc *desc, int M) {
-    return desc && M > 0 ? (size_t)M * kSavedPerSample : 0;
+    Shape s;
+    return desc && M > 0 && shape_of(*desc, &s) ? (size_t)M * saved_per_sample(s.D, s.W) : 0;
 }
 extern "C" size_t zest_mlp_train_workspace_floats(const zest_mlp_desc *desc, int M) {
-    return desc && M > 0 ? (size_t)M * kWorkPerSample + kPartialFloats : 0;
+    Shape s;
+    return desc && M > 0 && shape_of(*desc, &s) ? (size_t)M * work_per_sample(s.W) + kPartialFloats : 0;
 }
 
 #define RB(x)                                                       \
@@ -245,7 +258,9 @@ extern "C" int zest_mlp_train_fwd(const zest_mlp_desc *desc, const float *const 
                                   int M, float *saved, float *workspace, float *out, void *stream) {
     ZEST_CHECK_ARG(desc && params && x && saved && workspace && out && M > 0, "zest_mlp_train_fwd: bad argument");
     ZEST_CHECK_ARG(desc->net_type == 0 || desc->net_type == 2, "zest_mlp_train_fwd: net_type must be 0 or 2");
-    const Shape s = shape_of(*desc);
+    Shape s;
+    if (!shape_of(*desc, &s)) return (int)hipErrorInvalidValue;
+    const int D = s.D, W = s.W, HW = s.HW;
     hipStream_t st = (hipStream_t)stream;
     rocblas_handle h = handle_for(st);
     ZEST_CHECK_ARG(h, "zest_mlp_train_fwd: cannot create a rocBLAS handle");
@@ -253,8 +268,8 @@ extern "C" int zest_mlp_train_fwd(const zest_mlp_desc *desc, const float *const 
     for (int i = 0; i < ZEST_P_COUNT; i++) p.w[i] = params[2 * i], p.b[i] = params[2 * i + 1];
     const long long MW = (long long)M * W;
     float *pre[8];
-    for (int l = 0; l < 8; l++) pre[l] = saved + (size_t)l * MW;
-    float *mbuf = saved + 8 * MW, *featl = saved + 9 * MW, *hvpre = saved + 10 * MW;
+    for (int l = 0; l < D; l++) pre[l] = saved + (size_t)l * MW;
+    float *mbuf = saved + D * MW, *featl = saved + (D + 1) * MW, *hvpre = saved + (D + 2) * MW;
     float *actA = workspace, *actB = workspace + MW, *hp = workspace + 7 * MW + (long long)M * HW;
     const float *xp = x, *xf = x + s.P, *xv = x + s.P + s.F;
     const float *m = nullptr;
@@ -264,12 +279,12 @@ extern "C" int zest_mlp_train_fwd(const zest_mlp_desc *desc, const float *const 
         m = mbuf;
     }
     float *cur = actA, *nxt = actB;
-    for (int l = 0; l < 8; l++) {
+    for (int l = 0; l < D; l++) {
         if (l == 0) {
             RB(gemm_xwT(h, M, W, s.P, xp, s.C_in, p.w[0], s.P, pre[0], W, 0.f));
-        } else if (l == 5) {      // input = [pts | h]
-            RB(gemm_xwT(h, M, W, s.P, xp, s.C_in, p.w[5], W + s.P, pre[5], W, 0.f));
-            RB(gemm_xwT(h, M, W, W, cur, W, p.w[5] + s.P, W + s.P, pre[5], W, 1.f));
+        } else if (s.skip_in(l)) {      // input = [pts | h]
+            RB(gemm_xwT(h, M, W, s.P, xp, s.C_in, p.w[l], W + s.P, pre[l], W, 0.f));
+            RB(gemm_xwT(h, M, W, W, cur, W, p.w[l] + s.P, W + s.P, pre[l], W, 1.f));
         } else {
             RB(gemm_xwT(h, M, W, W, cur, W, p.w[l], W, pre[l], W, 0.f));
         }
@@ -320,7 +335,9 @@ extern "C" int zest_mlp_train_bwd(const zest_mlp_desc *desc, const float *const 
                                   float *workspace, float *g_x, float *const *g_params, void *stream) {
     ZEST_CHECK_ARG(desc && params && x && saved && out && g_out && workspace && g_params && M > 0,
                    "zest_mlp_train_bwd: bad argument");
-    const Shape s = shape_of(*desc);
+    Shape s;
+    if (!shape_of(*desc, &s)) return (int)hipErrorInvalidValue;
+    const int D = s.D, W = s.W, HW = s.HW;
     hipStream_t st = (hipStream_t)stream;
     rocblas_handle h = handle_for(st);
     ZEST_CHECK_ARG(h, "zest_mlp_train_bwd: cannot create a rocBLAS handle");
@@ -332,11 +349,11 @@ extern "C" int zest_mlp_train_bwd(const zest_mlp_desc *desc, const float *const 
     }
     const long long MW = (long long)M * W, MH = (long long)M * HW;
     const float *pre[8];
-    for (int l = 0; l < 8; l++) pre[l] = saved + (size_t)l * MW;
-    const float *mbuf = s.mod ? saved + 8 * MW : nullptr, *featl = saved + 9 * MW, *hvpre = saved + 10 * MW;
+    for (int l = 0; l < D; l++) pre[l] = saved + (size_t)l * MW;
+    const float *mbuf = s.mod ? saved + D * MW : nullptr, *featl = saved + (D + 1) * MW, *hvpre = saved + (D + 2) * MW;
     float *da = workspace + 2 * MW, *db_ = workspace + 3 * MW, *act = workspace + 4 * MW, *dm = workspace + 5 * MW;
     float *dfeat = workspace + 6 * MW, *dhv = workspace + 7 * MW, *dhp = dhv + MH;
-    const Ctx cx{h, st, workspace + (size_t)M * kWorkPerSample};
+    const Ctx cx{h, st, workspace + (size_t)M * work_per_sample(W)};
     const float *xp = x, *xf = x + s.P, *xv = x + s.P + s.F;
     float *gxp = g_x, *gxf = g_x ? g_x + s.P : nullptr;
     if (s.mod) EW(fill_kernel, MW, dm, MW, 0.f);
@@ -356,8 +373,8 @@ extern "C" int zest_mlp_train_bwd(const zest_mlp_desc *desc, const float *const 
     RB(gemm_dw(cx, M, HW, W, dhv, HW, featl, W, g.w[ZEST_P_VIEWS], W + s.V));
     RB(gemm_dw(cx, M, HW, s.V, dhv, HW, xv, s.C_in, g.w[ZEST_P_VIEWS] + W, W + s.V));
     RB(gemm_dx(h, M, HW, W, dhv, HW, p.w[ZEST_P_VIEWS], W + s.V, dfeat, W, 0.f));
-    // trunk output h7 = relu(mod(pre7, m)): feature_linear, alpha and the extra heads read it
-    EW(react_kernel, MW, pre[7], mbuf, act, MW, s.v2);
+    // trunk output h(D-1) = relu(mod(pre(D-1), m)): feature_linear, alpha and the extra heads read it
+    EW(react_kernel, MW, pre[D - 1], mbuf, act, MW, s.v2);
     RB(gemm_dw(cx, M, W, W, dfeat, W, act, W, g.w[ZEST_P_FEATURE], W));
     RB(col_sums(cx, M, W, dfeat, W, g.b[ZEST_P_FEATURE]));
     RB(gemm_dx(h, M, W, W, dfeat, W, p.w[ZEST_P_FEATURE], W, da, W, 0.f));
@@ -377,7 +394,7 @@ extern "C" int zest_mlp_train_bwd(const zest_mlp_desc *desc, const float *const 
     }
     // trunk, last layer first.  da = dL/d(act_l) on entry to layer l.
     float *dcur = da, *dnxt = db_;
-    for (int l = 7; l >= 0; l--) {
+    for (int l = D - 1; l >= 0; l--) {
         // dcur = dL/dpre_l, and its column sums = the bias gradient
         hipLaunchKernelGGL(zero_kernel, dim3(1), dim3(256), 0, st, g.b[l], W);
         hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3((M + kBwdRows - 1) / kBwdRows), dim3(W), 0, st, dcur, pre[l],
@@ -388,11 +405,11 @@ extern "C" int zest_mlp_train_bwd(const zest_mlp_desc *desc, const float *const 
             break;
         }
         EW(react_kernel, MW, pre[l - 1], mbuf, act, MW, s.v2);              // input of layer l
-        if (l == 5) {
-            RB(gemm_dw(cx, M, W, s.P, dcur, W, xp, s.C_in, g.w[5], W + s.P));
-            RB(gemm_dw(cx, M, W, W, dcur, W, act, W, g.w[5] + s.P, W + s.P));
-            if (g_x) RB(gemm_dx(h, M, W, s.P, dcur, W, p.w[5], W + s.P, gxp, s.C_in, 1.f));
-            RB(gemm_dx(h, M, W, W, dcur, W, p.w[5] + s.P, W + s.P, dnxt, W, 0.f));
+        if (s.skip_in(l)) {
+            RB(gemm_dw(cx, M, W, s.P, dcur, W, xp, s.C_in, g.w[l], W + s.P));
+            RB(gemm_dw(cx, M, W, W, dcur, W, act, W, g.w[l] + s.P, W + s.P));
+            if (g_x) RB(gemm_dx(h, M, W, s.P, dcur, W, p.w[l], W + s.P, gxp, s.C_in, 1.f));
+            RB(gemm_dx(h, M, W, W, dcur, W, p.w[l] + s.P, W + s.P, dnxt, W, 0.f));
         } else {
             RB(gemm_dw(cx, M, W, W, dcur, W, act, W, g.w[l], W));
             RB(gemm_dx(h, M, W, W, dcur, W, p.w[l], W, dnxt, W, 0.f));

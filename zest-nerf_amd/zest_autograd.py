@@ -166,9 +166,7 @@ def mlp_apply(net, x, time_codes=None, bf16=False):
     desc = mod._desc()
     named = mod.effective_parameters(time_codes)
     slots, params = [], []
-    for name, slot in zest_hip._PARAM_SLOTS:
-        if name == "pts_bias" and not desc.use_feat:
-            continue
+    for name, slot in zest_hip.param_slots(desc):
         slots.append(slot)
         params += [named[name + ".weight"], named[name + ".bias"]]
     extra = {zest_hip.HEAD_BLEND: [("w_linear", 13)],
@@ -176,7 +174,7 @@ def mlp_apply(net, x, time_codes=None, bf16=False):
     for name, slot in extra:
         slots.append(slot)
         params += [named[name + ".weight"], named[name + ".bias"]]
-    if bf16 and desc.net_type == 0:
+    if bf16 and desc.net_type == 0 and desc.is_default_shape:      # the MFMA training kernels' shape
         return MlpFn16.apply(x, desc, tuple(slots), *params)
     return MlpFn.apply(x, desc, tuple(slots), *params)
 

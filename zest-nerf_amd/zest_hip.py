@@ -29,7 +29,26 @@ _fp = C.POINTER(C.c_float)
 
 class MlpDesc(C.Structure):
     _fields_ = [("in_ch_pts", C.c_int32), ("in_ch_feat", C.c_int32), ("in_ch_views", C.c_int32),
-                ("use_feat", C.c_int32), ("net_type", C.c_int32), ("head", C.c_int32)]
+                ("use_feat", C.c_int32), ("net_type", C.c_int32), ("head", C.c_int32),
+                ("depth", C.c_int32), ("width", C.c_int32), ("skip_mask", C.c_int32)]
+
+    @property
+    def D(self):
+        return self.depth or 8
+
+    @property
+    def W(self):
+        return self.width or 256
+
+    @property
+    def skips(self):
+        """Reference `skips` list (networks.py:93-100): layer i+1 takes [pts | h] for i in skips."""
+        mask = self.skip_mask if (self.depth or self.width or self.skip_mask) else 1 << 4
+        return [i for i in range(8) if mask >> i & 1]
+
+    @property
+    def is_default_shape(self):
+        return self.D == 8 and self.W == 256 and self.skips == [4]
 
     @property
     def in_ch(self):
@@ -120,8 +139,8 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)           # AttributeError if the header and library disagree
             fn.restype, fn.argtypes = res, args
-        if L.zest_abi_version() != 2:
-            raise RuntimeError("libzest_hip.so ABI %d != 2: rebuild it (python zest-nerf_amd/build_hip.py)"
+        if L.zest_abi_version() != 3:
+            raise RuntimeError("libzest_hip.so ABI %d != 3: rebuild it (python zest-nerf_amd/build_hip.py)"
                                % L.zest_abi_version())
         _lib = L
     return _lib
@@ -572,6 +591,8 @@ def mlp_pack(desc, precision, params):
     keep = [(_dev(p, "param") if p is not None else None) for p in params]
     arr = (_vp * (2 * P_COUNT))(*[_ptr(p) for p in keep])
     nbytes = mlp_packed_bytes(desc, precision)
+    if nbytes == 0:                      # shape / precision the kernels refuse: the library says which
+        raise RuntimeError("zest_mlp_packed_bytes: %s" % (lib().zest_last_error() or b"").decode())
     packed = torch.empty(nbytes, device=dev, dtype=torch.uint8)
     _check(lib().zest_mlp_pack(C.byref(desc), int(precision), arr, _ptr(packed),
                                torch.cuda.current_stream(dev).cuda_stream), "zest_mlp_pack")
@@ -602,6 +623,12 @@ _PARAM_SLOTS = [("pts_linears.%d" % i, i) for i in range(8)] + [
     ("rgb_linear", 12)]
 
 
+def param_slots(desc):
+    """(module name, ZEST_P_* slot) of the Linears every net of this shape has (heads apart)."""
+    return [(n, s) for n, s in _PARAM_SLOTS
+            if not (n == "pts_bias" and not desc.use_feat) and not (s < 8 and s >= desc.D)]
+
+
 def param_table(state, desc, prefix="nerf."):
     """Order the nn.Linear tensors of a reference-layout state dict as zest_mlp_pack expects."""
     tab = [None] * (2 * P_COUNT)
@@ -609,9 +636,7 @@ def param_table(state, desc, prefix="nerf."):
     def put(slot, name):
         tab[2 * slot] = state[prefix + name + ".weight"]
         tab[2 * slot + 1] = state[prefix + name + ".bias"]
-    for name, slot in _PARAM_SLOTS:
-        if name == "pts_bias" and not desc.use_feat:
-            continue
+    for name, slot in param_slots(desc):
         put(slot, name)
     if desc.head == HEAD_BLEND:
         put(13, "w_linear")

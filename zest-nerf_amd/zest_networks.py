@@ -84,11 +84,19 @@ class _MlpBase(nn.Module):
     """Parameters of the width-W MLP + the packed-weight cache for the MFMA kernels."""
 
     def _build(self, D, W, input_ch, input_ch_views, input_ch_feat, skips, use_viewdirs):
-        if D != 8 or W != 256 or list(skips) != [4] or not use_viewdirs:
+        # Reference networks.py:93-100 builds any D / W / skips.  The shipped shape (8 / 256 / [4]: every config
+        # and opt.py:54-57's defaults) runs on the MFMA engine in every precision; other shapes run on the
+        # exact-product fp32 kernel and the fp32 training path (engine_precision below).
+        skips = [int(i) for i in skips]
+        if not use_viewdirs:
+            raise NotImplementedError("zest MLP: use_viewdirs=False (never built by the reference: networks.py:336-345 "
+                                      "passes use_viewdirs=True)")
+        if not 2 <= D <= 8 or W not in (64, 128, 192, 256) or any(i < 0 or i > D - 2 for i in skips):
             raise NotImplementedError(
-                "zest MLP kernels cover the shipped architecture only: D=8, W=256, skips=[4], "
-                "use_viewdirs=True (got D=%s W=%s skips=%s viewdirs=%s)" % (D, W, skips, use_viewdirs))
+                "zest MLP kernels cover 2 <= D <= 8, W in {64,128,192,256}, skips within 0 .. D-2 "
+                "(got D=%s W=%s skips=%s)" % (D, W, skips))
         self.D, self.W, self.skips, self.use_viewdirs = D, W, skips, use_viewdirs
+        self.default_shape = D == 8 and W == 256 and sorted(set(skips)) == [4]
         self.in_ch_pts, self.in_ch_views, self.in_ch_feat = input_ch, input_ch_views, input_ch_feat
         # Encoded point = 63 (xyz) or 84 (xyzt) channels; anything beyond 63 that is not 84 is the
         # Neural3D time code (reference train.py:112-113: input_ch += time_code_dim, static net).  The
@@ -113,13 +121,24 @@ class _MlpBase(nn.Module):
     def _desc(self):
         raise NotImplementedError
 
+    def _mk_desc(self, in_ch_pts, use_feat, net_type, head):
+        if self.default_shape:          # zeros = the default shape: one plan / packed-weight cache entry
+            return zest_hip.MlpDesc(in_ch_pts, self.in_ch_feat, self.in_ch_views, use_feat, net_type, head)
+        return zest_hip.MlpDesc(in_ch_pts, self.in_ch_feat, self.in_ch_views, use_feat, net_type, head,
+                                self.D, self.W, sum(1 << i for i in set(self.skips)))
+
+    def engine_precision(self, prec):
+        """Operand type this net can run `prec` in: the MFMA engine (bf16 / fp16 / split fp16) is
+        written for the shipped shape; other depths / widths / skips run exact fp32 products."""
+        return prec if self.default_shape else zest_hip.PREC_F32
+
     def effective_parameters(self, time_codes=None):
         """{name: tensor} of the 63/84-channel net the kernels run.  Without time-code channels these
         are the parameters themselves.  With them (in_ch_time = T > 0) `time_codes` ([T] or [1,T], the
         frame's latent code BEFORE the sigmoid, reference renderer.py:269-273) is folded in:
             layer 0:  W0 [256, P+T]      -> W0[:, :P],               b0 + W0[:, P:] sigmoid(tc)
             layer 5:  W5 [256, P+T+256]  -> W5[:, :P] | W5[:, P+T:],  b5 + W5[:, P:P+T] sigmoid(tc)
-        (the skip layer's input is [point | time code | h], networks.py:182).  Plain torch ops: under
+        (layer i+1 for each i in skips; the skip layer's input is [point | time code | h], networks.py:182).  Plain torch ops: under
         autograd the gradients reach the original parameters and the code."""
         params = self.__dict__.get("_zest_params")
         if params is None:
@@ -135,11 +154,14 @@ class _MlpBase(nn.Module):
         tc = torch.sigmoid(time_codes.float()).reshape(-1)
         if tc.numel() != T:
             raise RuntimeError("zest MLP: time code has %d values, the net expects %d" % (tc.numel(), T))
-        w0, w5 = named["pts_linears.0.weight"], named["pts_linears.5.weight"]
+        w0 = named["pts_linears.0.weight"]
         named["pts_linears.0.weight"] = w0[:, :P].contiguous()
         named["pts_linears.0.bias"] = named["pts_linears.0.bias"] + w0[:, P:] @ tc
-        named["pts_linears.5.weight"] = torch.cat([w5[:, :P], w5[:, P + T:]], 1)
-        named["pts_linears.5.bias"] = named["pts_linears.5.bias"] + w5[:, P:P + T] @ tc
+        for i in set(self.skips):
+            k = "pts_linears.%d" % (i + 1)
+            w = named[k + ".weight"]
+            named[k + ".weight"] = torch.cat([w[:, :P], w[:, P + T:]], 1)
+            named[k + ".bias"] = named[k + ".bias"] + w[:, P:P + T] @ tc
         return named
 
     def packed(self, precision, desc=None, time_codes=None):
@@ -177,8 +199,8 @@ class _MlpBase(nn.Module):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             raise NotImplementedError("forward_alpha: inference only (the reference never calls it: "
                                       "renderer.py:295 sets alpha_only only when no direction is given)")
-        desc = zest_hip.MlpDesc(self.in_ch_pts, self.in_ch_feat, self.in_ch_views, 1, net_type, zest_hip.HEAD_NONE)
-        prec = inference_precision(resolve_precision())
+        desc = self._mk_desc(self.in_ch_pts, 1, net_type, zest_hip.HEAD_NONE)
+        prec = self.engine_precision(inference_precision(resolve_precision()))
         xin = torch.cat([x, x.new_zeros(*x.shape[:-1], self.in_ch_views)], -1)
         alpha = zest_hip.mlp_fwd(desc, prec, self.packed(prec, desc), xin)[..., 3:4]
         return torch.relu(alpha) if relu else alpha
@@ -196,7 +218,7 @@ class _MlpBase(nn.Module):
             raise NotImplementedError("zest MLP: a net with time-code channels runs through rendering(..., time_codes=...), "
                                       "which folds the frame's code into the biases of layers 0 and 5")
         desc = self._desc()
-        prec = inference_precision(resolve_precision()) if precision is None else precision
+        prec = self.engine_precision(inference_precision(resolve_precision()) if precision is None else precision)
         return zest_hip.mlp_fwd(desc, prec, self.packed(prec), x)
 
     def forward(self, x):
@@ -222,8 +244,7 @@ class Renderer(_MlpBase):
         head = zest_hip.HEAD_NONE
         if self.predict_sceneflow:
             head = zest_hip.HEAD_BLEND if self.static else zest_hip.HEAD_DYNAMIC
-        return zest_hip.MlpDesc(self.in_ch_pe, self.in_ch_feat, self.in_ch_views,
-                                int(bool(self.use_mvs)), 0, head)
+        return self._mk_desc(self.in_ch_pe, int(bool(self.use_mvs)), 0, head)
 
     def forward_alpha(self, x):
         """relu(alpha_linear(trunk(x))) with multiplicative modulation (reference networks.py:134-147)."""
@@ -239,8 +260,7 @@ class Renderer_linear(_MlpBase):
         self._build(D, W, input_ch, input_ch_views, input_ch_feat, skips, use_viewdirs)
 
     def _desc(self):
-        return zest_hip.MlpDesc(self.in_ch_pe, self.in_ch_feat, self.in_ch_views, 1, 2,
-                                zest_hip.HEAD_NONE)
+        return self._mk_desc(self.in_ch_pe, 1, 2, zest_hip.HEAD_NONE)
 
     def forward_alpha(self, x):
         """alpha_linear(trunk(x)), additive modulation, no activation (reference networks.py:266-280)."""

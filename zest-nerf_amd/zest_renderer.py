@@ -211,7 +211,10 @@ def rendering(args, rays_pts, rays_ndc, depth_candidates, rays_dir,
     # Fused single-launch plan: inference-shaped calls that read per-ray maps only.  fp32 mode runs
     # it on split-fp16 operand pairs (fp32-class results); a call that records a gradient takes the
     # complete plan below, whose stages have backward kernels.
-    if getattr(args, "zest_maps_only", False) and (val or not scene_flow) and not train:
+    # The engine kernels are written for the shipped MLP shape (D=8, W=256, skips=[4]); a net of another
+    # shape takes the complete plan with the exact-product fp32 MLP kernel.
+    engine_shape = net_s.nerf.default_shape and (network_fn_dy is None or _net(network_fn_dy, "network_fn_dy").nerf.default_shape)
+    if getattr(args, "zest_maps_only", False) and (val or not scene_flow) and not train and engine_shape:
         fused_prec = zest_hip.PREC_F16X3 if prec == zest_hip.PREC_F32 else prec     # no exact-product fused kernel
         return _render_maps_fused(fused_prec, time_codes, rays_ndc, ndc, pts, z, dirs, net_s, network_fn_dy, scene_flow,
                                   volume_feature_static, volume_feature_dynamic, imgs,
@@ -225,7 +228,8 @@ def rendering(args, rays_pts, rays_ndc, depth_candidates, rays_dir,
     def mlp(net, x, tc=None):
         if train:
             return za.mlp_apply(net, x, tc, bf16=train16)
-        return zest_hip.mlp_fwd(net.desc(), mlp_prec, net.packed(mlp_prec, tc), x)
+        p = net.nerf.engine_precision(mlp_prec)
+        return zest_hip.mlp_fwd(net.desc(), p, net.packed(p, tc), x)
 
     def encode(views, volume, ndc3, t=None):
         if train:

@@ -316,9 +316,10 @@ int zest_mlp_fwd(const zest_mlp_desc *desc, int precision, const void *packed,
  * (the packed weights must have been packed for it); _F16X3 is the fp32 mode of this path
  * (results within 1e-4 abs / 1e-3 rel of the fp32 reference).  A ray is cut into blocks of 32
  * samples (16 for _F16X3), one per wave of an 8-wave workgroup pass.  The blocks of a ray are
- * chained inside the launch when a pass holds whole rays (ray-aligned passes: up to 8 blocks
- * per ray, taken whenever that costs no extra round of passes on the device); otherwise
- * (dense passes) by a second tiny launch reading the block records from `workspace`.
+ * chained inside the launch: a workgroup owns a range of whole rays and carries a ray that spans
+ * two of its passes in LDS (any S); only where that would need more rounds of passes than spreading
+ * all blocks over the device (a few long rays) are the blocks chained by a second tiny launch reading
+ * the block records from `workspace` (see zest_render_fused_pass_shape).
  * out [R,16]: 0-2 rgb_map, 3 depth_map, 4 acc_map; with the dynamic net also
  * 5-7 rgb_map_ref, 8 depth_map_ref, 9-11 rgb_map_ref_dy, 12 depth_map_ref_dy,
  * 13 weights_map_dd; 14,15 reserved. */
@@ -336,13 +337,16 @@ typedef struct zest_view_set {
 size_t zest_render_fused_workspace(int R, int S);
 
 /* Pass shape of zest_render_fused_fwd for the whole process: 0 = chosen per launch (default),
- * 1 = dense passes + combine launch, 2 = ray-aligned passes wherever a ray fits one pass.
+ * 1 = dense (equal shares of all blocks per workgroup + the combine launch), 2 = ray ranges.
  * Results are identical; a knob for tests and measurements. */
 int zest_render_fused_set_passes(int shape);
 /* What zest_render_fused_fwd will do for R rays of S samples on a device of `cus` compute units (0: the
- * current device): *rays_per_pass > 0 = ray-aligned passes of that many whole rays, finished in the
- * kernel; 0 = dense passes + the combine launch; *n_pass = workgroup passes.  Host arithmetic only. */
-int zest_render_fused_pass_shape(int R, int S, int precision, int cus, int *rays_per_pass, int *n_pass);
+ * current device): *ray_ranges = 1: every workgroup owns a range of whole rays, walks their blocks 8 at
+ * a time and finishes the rays in the kernel, carrying a ray that spans two passes in LDS (the default
+ * wherever it needs no more rounds than the dense shape); 0 = dense + the combine launch.
+ * *n_wg (may be NULL) = workgroups launched, *rounds (may be NULL) = passes of the busiest workgroup.
+ * Host arithmetic only. */
+int zest_render_fused_pass_shape(int R, int S, int precision, int cus, int *ray_ranges, int *n_wg, int *rounds);
 
 int zest_render_fused_fwd(const float *ndc, const float *pts, const float *z,
                           const float *rays_dir, int R, int S,

@@ -59,16 +59,20 @@ def test_library_is_not_older_than_its_sources():
 
 
 def test_fused_pass_shapes_for_the_baseline_batches():
-    """Host arithmetic of the fused renderer's pass shape (no GPU call: cus given).  The headline batch and the
-    strong-scaled configs[3] shard (512 rays x 192 samples per GPU: 6 blocks per ray) finish their rays in the kernel
-    (no block records in HBM, no second launch); the full 4096 x 192 batch on one GPU takes dense passes, where
-    ray-aligned ones would cost 16 rounds of passes instead of 12."""
+    """Host arithmetic of the fused renderer's pass shape (no GPU call: cus given): (ray ranges?, workgroups, rounds).
+    Every baseline batch finishes its rays in the kernel (a range of whole rays per workgroup, no block records in
+    HBM, no second launch) with a block for every wave of every pass but a workgroup's last: the strong-scaled
+    configs[3] shard (512 rays x 192 samples per GPU: 6 blocks per ray) runs an 8-block and a 4-block pass per
+    workgroup, the full 4096 x 192 batch 12 rounds (whole-ray passes: 16)."""
     sys.path.insert(0, os.path.join(ROOT, "zest-nerf_amd"))
     import zest_hip as zh
-    assert zh.fused_pass_shape(1024, 128, zh.PREC_BF16, 256) == (2, 512)          # 4 blocks per ray: 2 rays per pass
-    assert zh.fused_pass_shape(1024, 128, zh.PREC_F16X3, 256) == (1, 1024)        # 16-sample blocks: 8 per ray
-    assert zh.fused_pass_shape(512, 192, zh.PREC_BF16, 256) == (1, 512)           # 6 of 8 waves busy, 2 rounds either way
-    assert zh.fused_pass_shape(4096, 192, zh.PREC_BF16, 256) == (0, 3072)         # dense: 12 rounds instead of 16
-    assert zh.fused_pass_shape(8192, 128, zh.PREC_F16, 256) == (2, 4096)
-    assert zh.fused_pass_shape(7, 300, zh.PREC_BF16, 256) == (0, 9)               # 10 blocks per ray: more than a pass
-    assert zh.fused_pass_shape(0, 64, zh.PREC_BF16, 256) == (4, 0)
+    assert zh.fused_pass_shape(1024, 128, zh.PREC_BF16, 256) == (1, 256, 2)        # 4 rays = 16 blocks per workgroup
+    assert zh.fused_pass_shape(1024, 128, zh.PREC_F16X3, 256) == (1, 256, 4)       # 16-sample blocks: 8 per ray
+    assert zh.fused_pass_shape(512, 192, zh.PREC_BF16, 256) == (1, 256, 2)         # 2 rays = 12 blocks: passes of 8 + 4
+    assert zh.fused_pass_shape(4096, 192, zh.PREC_BF16, 256) == (1, 256, 12)       # 16 rays = 96 blocks: 12 full passes
+    assert zh.fused_pass_shape(8192, 128, zh.PREC_F16, 256) == (1, 256, 16)
+    assert zh.fused_pass_shape(100, 64, zh.PREC_BF16, 256) == (1, 100, 1)          # fewer rays than CUs: one each
+    assert zh.fused_pass_shape(7, 300, zh.PREC_BF16, 256) == (0, 9, 1)             # a few long rays: spread the blocks
+    assert zh.fused_pass_shape(600, 300, zh.PREC_BF16, 256) == (0, 250, 3)         # ranges would need a 4th round
+    assert zh.fused_pass_shape(2048, 300, zh.PREC_BF16, 256) == (1, 256, 10)       # 10 blocks per ray, carried over passes
+    assert zh.fused_pass_shape(0, 64, zh.PREC_BF16, 256)[1:] == (0, 0)

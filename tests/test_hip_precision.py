@@ -170,23 +170,23 @@ def test_fused_v2_net(hip, mode):
 
 # ------------------------------------------------------------------------------ pass shapes
 @pytest.mark.parametrize("mode", ["f16x3", "bf16"])
-@pytest.mark.parametrize("R,S", [(40, 96), (40, 192), (8, 250), (9, 300), (300, 192)])
+@pytest.mark.parametrize("R,S", [(40, 96), (40, 192), (8, 250), (9, 300), (300, 192), (1100, 160)])
 def test_pass_shapes_agree(hip, R, S, mode, monkeypatch):
-    """bpr = 3, 6, 8 (aligned passes with idle waves), > 8 waves per ray (dense only) and a batch
-    large enough that the dispatcher picks dense passes by itself: the in-kernel ray finishing and
-    the HBM-record + combine launch give the same maps bit for bit, with both nets (a dynamic
-    case reaches fused_combine_kernel's blended records), and match the oracle in fp32 mode."""
+    """3, 5, 6, 8 blocks per ray, more than 8 (a ray spans passes) and batches that give a workgroup several
+    rays (rays straddling its passes; waves without a block in its last pass): ray ranges with the in-kernel
+    carry and the dense shape with HBM records + combine launch give the same maps bit for bit, with both nets
+    (a dynamic case reaches the blended records), and match the oracle in fp32 mode."""
     import zest_hip
     sc = gc.render_inputs(2100 + R + S, R=R, S=S, V=3, use_mvs=True, scene_flow=True, use_mvs_dy=True)
     c = dict(val=True)
     kw = dict(precision=32) if mode == "f16x3" else dict(precision=16, dtype16=mode)
     outs = {}
-    for shape in ("dense", "aligned", None):
+    for shape in ("dense", "ranges", None):
         # the library reads ZEST_FUSED_PASSES once per process: use its setter instead of the environment
         zest_hip.set_fused_passes(shape)
         outs[shape] = render_scene(sc, c, maps_only=True, **kw)["zest_packed_maps"].clone()
     zest_hip.set_fused_passes(None)
-    assert torch.equal(outs["dense"], outs["aligned"]) and torch.equal(outs["dense"], outs[None])
+    assert torch.equal(outs["dense"], outs["ranges"]) and torch.equal(outs["dense"], outs[None])
     if mode == "f16x3":
         want = orun.oracle_render(c, sc)
         got = render_scene(sc, c, maps_only=True, **kw)

@@ -8,9 +8,12 @@
 // and the raw colour/density land on lanes 0-15 of each column block; one v_permlane16_swap
 // per value lines the 32 samples up on lanes 0-31, where a shuffle scan composites the block.
 // Each block is composited with entry transmittance 1 and leaves an 80-byte record; the records
-// of a ray are chained into the per-ray maps (64 B per ray) either right here - when the 8
-// blocks of a pass hold whole rays (S <= 256 in steps that divide 8 blocks), the records never
-// leave LDS - or by a second tiny kernel (fused_combine_kernel) from an HBM workspace.
+// of a ray are chained into the per-ray maps (64 B per ray) right here: a workgroup owns a contiguous
+// range of whole rays and walks their blocks 8 at a time, so the records of a pass sit in LDS and a ray
+// that continues into the workgroup's next pass carries its running sums there (any S, any number of
+// blocks per ray).  The other pass shape (taken for a few long rays on a big device, or forced with
+// zest_render_fused_set_passes) splits ALL blocks evenly over the workgroups, rays notwithstanding: the
+// records then go to an HBM workspace and a second tiny kernel (fused_combine_kernel) chains them.
 //
 // Replaces rendering(..., val=True) of the reference (renderer.py:579-626 with the early
 // return at :444-445): prepare_pts / prepare_dynamic_pts, gen_pts_feats, run_network,
@@ -44,17 +47,17 @@ struct FusedArgs {
     float *partials;                      // [R*bpr, kPartialFloats] workspace
     float *out;                           // [R,16]
     unsigned long long *stamps;           // diagnostic builds (ZEST_STAMPS): 8 u64 per wave, else null
-    int rays_per_pass;                    // > 0: a pass holds this many whole rays and finishes them itself
+    int ray_ranges;                       // 1: workgroup w of gridDim.x owns the rays [w R / n, (w+1) R / n) and finishes
+                                          //    them in the kernel (a ray spanning two passes is carried in LDS);
+                                          // 0: it owns an equal share of ALL blocks, records go to `partials`
 };
 
-// Chains the per-block records of one ray (exit transmittance + weighted sums, entry
-// transmittance 1 each) into the per-ray maps: column layout of include/zest_render.h.
-template <class Rec>
-__device__ __forceinline__ void combine_ray(Rec rec, int bpr, bool dyn, int white_bkgd, float *__restrict__ out_row) {
+// Running composite of one ray over its block records (exit transmittance + weighted sums, entry
+// transmittance 1 each): the blocks are chained in order, so every pass shape sums in the same order.
+struct RayState {
     float Ts = 1.f, Tb = 1.f, Tf = 1.f;
     float s[5] = {0, 0, 0, 0, 0}, bl[5] = {0, 0, 0, 0, 0}, fg[4] = {0, 0, 0, 0};
-    for (int b = 0; b < bpr; b++) {
-        const float *p = rec(b);
+    __device__ __forceinline__ void chain(const float *p, bool dyn) {
 #pragma unroll
         for (int i = 0; i < 5; i++) s[i] += Ts * p[1 + i];
         Ts *= p[0];
@@ -67,12 +70,38 @@ __device__ __forceinline__ void combine_ray(Rec rec, int bpr, bool dyn, int whit
             Tf *= p[12];
         }
     }
-    float4 *o = reinterpret_cast<float4 *>(out_row);
-    const float bg = white_bkgd ? 1.0f - s[4] : 0.0f;
-    o[0] = make_float4(s[0] + bg, s[1] + bg, s[2] + bg, s[3]);
-    o[1] = make_float4(s[4], bl[0], bl[1], bl[2]);
-    o[2] = make_float4(bl[3], fg[0], fg[1], fg[2]);
-    o[3] = make_float4(fg[3], bl[4], 0.f, 0.f);
+    // per-ray maps: column layout of include/zest_render.h
+    __device__ __forceinline__ void emit(int white_bkgd, float *__restrict__ out_row) const {
+        float4 *o = reinterpret_cast<float4 *>(out_row);
+        const float bg = white_bkgd ? 1.0f - s[4] : 0.0f;
+        o[0] = make_float4(s[0] + bg, s[1] + bg, s[2] + bg, s[3]);
+        o[1] = make_float4(s[4], bl[0], bl[1], bl[2]);
+        o[2] = make_float4(bl[3], fg[0], fg[1], fg[2]);
+        o[3] = make_float4(fg[3], bl[4], 0.f, 0.f);
+    }
+    // the open ray of a workgroup between two of its passes (kCarryFloats floats in LDS)
+    __device__ __forceinline__ void save(float *c) const {
+        c[0] = Ts, c[1] = Tb, c[2] = Tf;
+#pragma unroll
+        for (int i = 0; i < 5; i++) c[3 + i] = s[i], c[8 + i] = bl[i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) c[13 + i] = fg[i];
+    }
+    __device__ __forceinline__ void load(const float *c) {
+        Ts = c[0], Tb = c[1], Tf = c[2];
+#pragma unroll
+        for (int i = 0; i < 5; i++) s[i] = c[3 + i], bl[i] = c[8 + i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) fg[i] = c[13 + i];
+    }
+};
+constexpr int kCarryFloats = 20;
+
+template <class Rec>
+__device__ __forceinline__ void combine_ray(Rec rec, int bpr, bool dyn, int white_bkgd, float *__restrict__ out_row) {
+    RayState st;
+    for (int b = 0; b < bpr; b++) st.chain(rec(b), dyn);
+    st.emit(white_bkgd, out_row);
 }
 
 // Positional-encoding operand for C coordinates and L (even) bands in plan position order
@@ -249,10 +278,10 @@ __device__ __forceinline__ float block_excl_prod(float f, int c, float *total) {
 // blocks).  A pass of the workgroup covers kFusedWaves blocks, one per wave: every wave runs the
 // full network on its block while all waves share the weight stream through the LDS ring.  Each
 // block is composited on its own with entry transmittance 1 and leaves a record (exit
-// transmittance + weighted sums); the records of a ray are chained in the pass itself when the
-// pass holds whole rays (a.rays_per_pass > 0: wave w has block w % bpr of ray
-// pass * rays_per_pass + w / bpr, waves beyond rays_per_pass * bpr idle), otherwise (dense
-// passes, wave w has block pass * kFusedWaves + w) by fused_combine_kernel from HBM.
+// transmittance + weighted sums).  A workgroup owns a contiguous range of blocks and takes them kFusedWaves at a
+// time (wave w of pass k: block 8 k + w of the range): whole rays (a.ray_ranges: the records of a ray are chained
+// in the pass itself, a ray that continues into the next pass carries its sums in LDS), or an equal share of
+// all blocks (the records go to HBM and fused_combine_kernel chains them).
 // NT_FEAT_*: stream tiles of the feature operand per row block (2 x its k-tiles; 0 = no features)
 #ifndef ZEST_FUSED_WG_PER_CU
 #define ZEST_FUSED_WG_PER_CU 1
@@ -282,7 +311,7 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
     __shared__ __attribute__((aligned(16))) char lds[kRingUnits * 1024 + 2 * kMaxViews * kCamStride * 4 +
                                                      kFusedWaves * 32 * 8 + 2 * kSlots * 4 +
                                                      kFusedWaves * kPartialFloats * 4 + kFusedWaves * 32 * 16 +
-                                                     kFdBytes + kStBytes];
+                                                     kFdBytes + kStBytes + 2 * kCarryFloats * 4];
     static_assert(sizeof(lds) <= 163840, "LDS budget of one workgroup per CU");
     float *cams_s = reinterpret_cast<float *>(lds + kRingUnits * 1024), *cams_d = cams_s + kMaxViews * kCamStride;
     float2 *zd_lds = reinterpret_cast<float2 *>(cams_d + kMaxViews * kCamStride);
@@ -293,6 +322,7 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
     float4 *x_lds = reinterpret_cast<float4 *>(rec_lds + kFusedWaves * kPartialFloats);    // [waves][32]
     uint4 *fd_lds = reinterpret_cast<uint4 *>(x_lds + kFusedWaves * 32);                   // [waves][CB][k-tile][part][64]
     float2 *st_lds = reinterpret_cast<float2 *>(reinterpret_cast<char *>(fd_lds) + kFdBytes);   // [waves][3][32]
+    float *carry_lds = reinterpret_cast<float *>(reinterpret_cast<char *>(st_lds) + kStBytes);  // [2][kCarryFloats]
 #ifdef ZEST_RING_FLAGS
     Ring::init_flags(ring_flags);
 #endif
@@ -311,20 +341,29 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
     tiles.init_addr();
     tiles.prologue();
 
-    const int n_blocks = a.R * a.bpr;
-    const int n_pass = a.rays_per_pass > 0 ? (a.R + a.rays_per_pass - 1) / a.rays_per_pass
-                                           : (n_blocks + kFusedWaves - 1) / kFusedWaves;
-    // this wave's block in pass `pass` (-1: none)
+    // The workgroup's blocks.  Workgroups are numbered so that those of one XCD (equal blockIdx % 8: one L2)
+    // own neighbouring ranges: the rays whose gathers touch neighbouring voxels and pixels (whole-image loops
+    // render contiguous pixel runs) meet in one L2 instead of being fetched into all eight.
+    const bool ranges = a.ray_ranges != 0;
+    const int n_wg = (int)gridDim.x;
+#ifndef ZEST_NO_XCD_ORDER
+    const int wg = n_wg % 8 == 0 ? (int)(blockIdx.x % 8) * (n_wg / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+#else
+    const int wg = (int)blockIdx.x;
+#endif
+    int range_b0, range_nb;                 // first block, number of blocks
+    if (ranges) {
+        range_b0 = (int)((long long)wg * a.R / n_wg) * a.bpr;
+        range_nb = (int)((long long)(wg + 1) * a.R / n_wg) * a.bpr - range_b0;
+    } else {
+        const int n_blocks = a.R * a.bpr;
+        const int share = ((n_blocks + kFusedWaves - 1) / kFusedWaves + n_wg - 1) / n_wg * kFusedWaves;   // whole passes
+        range_b0 = wg * share, range_nb = min(share, n_blocks - range_b0);
+    }
+    // this wave's block in pass `pass` of the workgroup (-1: none)
     auto block_of = [&](int pass) {
-        int g;
-        if (a.rays_per_pass > 0) {
-            const int ray = pass * a.rays_per_pass + wave / a.bpr;
-            g = (wave < a.rays_per_pass * a.bpr && ray < a.R) ? ray * a.bpr + wave % a.bpr : -1;
-        } else {
-            g = pass * kFusedWaves + wave;
-            if (g >= n_blocks) g = -1;
-        }
-        return __builtin_amdgcn_readfirstlane(g);
+        const int lb = pass * kFusedWaves + wave;
+        return __builtin_amdgcn_readfirstlane(lb < range_nb ? range_b0 + lb : -1);
     };
     // A lane's samples (column block cb: sample 16 cb + col of the block) are re-read from
     // global memory (L1/L2 hits) wherever they are needed instead of being held in registers
@@ -362,25 +401,19 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
 #else
 #define ZEST_STAMP(var) do {} while (0)
 #endif
-    // Pass order.  blockIdx % 8 labels the workgroups that share an XCD (and its L2): each label
-    // takes a contiguous run of passes, so the rays whose gathers touch neighbouring voxels and
-    // pixels (whole-image loops render contiguous pixel runs) meet in one L2 instead of being
-    // fetched into all eight.  Falls back to a plain grid stride when the grid is not a multiple of 8.
-#ifndef ZEST_NO_XCD_ORDER
-    const bool xcd_order = gridDim.x % 8 == 0;
-#else
-    const bool xcd_order = false;
-#endif
-    const int per_label = xcd_order ? (n_pass + 7) / 8 : n_pass;
-    const int pass_base = xcd_order ? (int)(blockIdx.x % 8) * per_label : 0;
-    const int pass_step = xcd_order ? (int)(gridDim.x / 8) : (int)gridDim.x;
-    for (int k = xcd_order ? (int)(blockIdx.x / 8) : (int)blockIdx.x; k < per_label; k += pass_step) {
-        const int pass = pass_base + k;
-        if (pass >= n_pass) break;
+    for (int k = 0; k * kFusedWaves < range_nb; k++) {
+        const int pass = k;
 #ifdef ZEST_STAMPS
         unsigned long long st_last = __builtin_amdgcn_s_memtime();
         st_n++;
 #endif
+        const int g = block_of(pass);
+        // A wave without a block (the tail of the workgroup's range) only keeps the weight ring in step - its
+        // DMA share and the rendezvous of every chunk - and leaves the matrix pipe of its SIMD to its partner
+        // wave, which then runs the network about twice as fast.
+        if (__builtin_expect(g < 0, 0)) {
+            tiles.finish(0, UNITS_S + UNITS_D);
+        } else {
         // The lane index is made opaque once per pass: every per-lane address below (samples, LDS
         // parking areas, record slots) is then recomputed in the pass - a handful of VALU instructions -
         // instead of being hoisted out of the loop as ~25 loop-invariant VGPRs that the two-net kernels
@@ -388,7 +421,6 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
         int lane = lane0;
         asm volatile("" : "+v"(lane));
         const int col = lane & 15, grp = lane >> 4, cbs = lane & (BS - 1);
-        const int g = block_of(pass);
         int unit = 0;
         f32x4 head_s[CB], rgb_s[CB], head_d[CB], rgb_d[CB];
         // direction operand of net `n`, built when the engine reaches the view layer
@@ -562,21 +594,31 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
         }
         if (lane == 0 && g >= 0) {
             // records go to HBM for combine_kernel, or stay in LDS when the pass holds whole rays
-            float4 *o = a.rays_per_pass > 0 ? reinterpret_cast<float4 *>(rec_lds + wave * kPartialFloats)
-                                            : reinterpret_cast<float4 *>(a.partials + (size_t)g * kPartialFloats);
+            float4 *o = ranges ? reinterpret_cast<float4 *>(rec_lds + wave * kPartialFloats)
+                               : reinterpret_cast<float4 *>(a.partials + (size_t)g * kPartialFloats);
 #pragma unroll
             for (int i = 0; i < (DYN ? 5 : 2); i++)
                 o[i] = make_float4(rec[4 * i], rec[4 * i + 1], rec[4 * i + 2], rec[4 * i + 3]);
         }
-        if (a.rays_per_pass > 0) {
-            // The blocks of a ray sit in consecutive waves of this pass: after one rendezvous the
-            // wave holding a ray's first block chains the records (80 B each, in LDS) and writes
-            // the ray's maps - no record traffic, no second launch.  The next pass cannot reach
-            // this point before every wave has passed the ring's chunk barriers, i.e. has left it.
+        }   // g >= 0
+        if (ranges) {
+            // The pass holds consecutive blocks of the workgroup's rays.  After one rendezvous the wave with a
+            // ray's first block OF THIS PASS chains that ray's records of this pass (80 B each, in LDS) - onto
+            // the sums carried over from the previous pass if the ray began there (then it is wave 0) - and
+            // either writes the ray's maps or, if the ray continues, leaves the sums for the next pass.  The
+            // carry is double-buffered by pass parity: the wave that reads the old one and the wave that writes
+            // the new one may differ.  Blocks are chained in ray order, as fused_combine_kernel does.  The next pass
+            // cannot reach this point before every wave has passed the ring's chunk barriers, i.e. has left it.
             __syncthreads();
-            if (lane == 0 && g >= 0 && g % a.bpr == 0)
-                combine_ray([&](int b) { return rec_lds + (wave + b) * kPartialFloats; }, a.bpr, DYN,
-                            a.white_bkgd, a.out + (size_t)(g / a.bpr) * 16);
+            const int rb = g >= 0 ? g % a.bpr : 0;                       // block within its ray
+            if (lane0 == 0 && g >= 0 && (wave == 0 || rb == 0)) {
+                RayState st;
+                if (rb != 0) st.load(carry_lds + ((k + 1) & 1) * kCarryFloats);
+                const int n = min(a.bpr - rb, kFusedWaves - wave);     // this ray's blocks in this pass
+                for (int b = 0; b < n; b++) st.chain(rec_lds + (wave + b) * kPartialFloats, DYN);
+                if (rb + n == a.bpr) st.emit(a.white_bkgd, a.out + (size_t)(g / a.bpr) * 16);
+                else st.save(carry_lds + (k & 1) * kCarryFloats);
+            }
         }
         ZEST_STAMP(st_comp);
         tiles.next_pass();

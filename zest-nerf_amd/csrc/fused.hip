@@ -62,21 +62,26 @@ constexpr size_t kStampBytes = 1024 * 8 * 8 * 8;       // diagnostic builds: 8 u
 constexpr size_t kStampBytes = 0;
 #endif
 
-static int g_pass_shape = 0;       // 0: chosen per launch, 1: dense passes, 2: ray-aligned passes
+static int g_pass_shape = 0;       // 0: chosen per launch, 1: equal block shares (dense), 2: ray ranges
 
 extern "C" int zest_render_fused_set_passes(int shape) {
-    ZEST_CHECK_ARG(shape >= 0 && shape <= 2, "zest_render_fused_set_passes: shape must be 0 (auto), 1 (dense) or 2 (aligned)");
+    ZEST_CHECK_ARG(shape >= 0 && shape <= 2,
+                   "zest_render_fused_set_passes: shape must be 0 (auto), 1 (dense: equal block shares) or 2 (ray ranges)");
     g_pass_shape = shape;
     return 0;
 }
 
-// Pass shape.  Dense: the blocks of all rays in order, kFusedWaves per pass, block records to the
-// workspace and a second tiny launch chains them.  Ray-aligned: a pass holds kFusedWaves / bpr whole
-// rays and finishes them itself (no record traffic, no second launch); waves beyond that idle.
-// Aligned is taken when it costs no extra round of passes on a device of `cus` compute units (always
-// when bpr divides kFusedWaves: S <= 32, 64, 128, 256 for 32-sample blocks).
-extern "C" int zest_render_fused_pass_shape(int R, int S, int precision, int cus, int *rays_per_pass, int *n_pass) {
-    ZEST_CHECK_ARG(R >= 0 && S >= 1 && zest::prec_is_engine(precision) && rays_per_pass && n_pass,
+// Pass shape (a pass = the kFusedWaves blocks the waves of a workgroup run through the network together).
+//   ray ranges (*ray_ranges = 1): workgroup w of n = min(cus, R) owns the rays [w R / n, (w+1) R / n) and walks their
+//     blocks kFusedWaves at a time; a ray that continues into the workgroup's next pass carries its sums in LDS.
+//     Every wave of every pass but a workgroup's last has a block, for any number of blocks per ray, and the rays
+//     are finished in the kernel.  Taken unless it needs more rounds than the dense shape.
+//   dense (0): every workgroup owns an equal share of ALL blocks (whole passes), rays notwithstanding; the block
+//     records go to the workspace and a second tiny launch chains them.  For a few long rays on a big device.
+// *n_wg: workgroups launched; *rounds: passes of the busiest workgroup.  Either may be NULL.
+extern "C" int zest_render_fused_pass_shape(int R, int S, int precision, int cus, int *ray_ranges, int *n_wg,
+                                            int *rounds) {
+    ZEST_CHECK_ARG(R >= 0 && S >= 1 && zest::prec_is_engine(precision) && ray_ranges,
                    "zest_render_fused_pass_shape: bad argument");
     if (cus <= 0) {
         int dev = 0;
@@ -86,13 +91,18 @@ extern "C" int zest_render_fused_pass_shape(int R, int S, int precision, int cus
     }
     const int bs = 16 * zest::fused_cb(precision), bpr = (S + bs - 1) / bs;
     const int W = zest::kFusedWaves;
-    const int dense_pass = zest_div_up((long long)R * bpr, W);
-    const int rpp = bpr <= W ? W / bpr : 0;
-    const int aligned_pass = rpp ? zest_div_up(R, rpp) : 0;
-    int take = (rpp && zest_div_up(aligned_pass, cus) <= zest_div_up(dense_pass, cus)) ? rpp : 0;
-    if (g_pass_shape == 1) take = 0;            // zest_render_fused_set_passes: dense
-    if (g_pass_shape == 2) take = rpp;          // ray-aligned wherever a ray fits a pass
-    *rays_per_pass = take, *n_pass = take ? aligned_pass : dense_pass;
+    // dense: P passes in all, ceil(P / G0) per workgroup, as many workgroups as that needs
+    const int P = zest_div_up((long long)R * bpr, W), G0 = P < cus ? P : cus;
+    const int dense_rounds = G0 ? zest_div_up(P, G0) : 0, dense_wg = G0 ? zest_div_up(P, dense_rounds) : 0;
+    // ray ranges: n workgroups, the busiest has ceil(R / n) rays
+    const int n = R < cus ? R : cus;
+    const int range_rounds = n ? zest_div_up((long long)zest_div_up(R, n) * bpr, W) : 0;
+    int take = range_rounds <= dense_rounds ? 1 : 0;
+    if (g_pass_shape == 1) take = 0;
+    if (g_pass_shape == 2) take = 1;
+    *ray_ranges = take;
+    if (n_wg) *n_wg = take ? n : dense_wg;
+    if (rounds) *rounds = take ? range_rounds : dense_rounds;
     return 0;
 }
 
@@ -145,9 +155,8 @@ extern "C" int zest_render_fused_fwd(const float *ndc, const float *pts, const f
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         cus = 256;
-    int n_pass = 0;
-    zest_render_fused_pass_shape(R, S, precision, cus, &a.rays_per_pass, &n_pass);
-    const int blocks = n_pass < cus ? n_pass : cus;                 // one workgroup per CU (128 KiB ring)
+    int blocks = 0;                        // workgroups: at most one per CU (128 KiB ring)
+    zest_render_fused_pass_shape(R, S, precision, cus, &a.ray_ranges, &blocks, nullptr);
     hipStream_t st = (hipStream_t)stream;
     const int key = (dyn ? 100 : 0) + nts * 10 + ntd;
     int rc = -1;
@@ -178,7 +187,7 @@ extern "C" int zest_render_fused_fwd(const float *ndc, const float *pts, const f
     }
 #undef ZEST_CASE
 #undef ZEST_CASE1
-    if (rc != 0 || a.rays_per_pass) return rc;
+    if (rc != 0 || a.ray_ranges) return rc;
     hipLaunchKernelGGL(zest::fused_combine_kernel, dim3(zest_div_up(R, 128)), dim3(128), 0, st,
                        a.partials, R, a.bpr, dyn ? 1 : 0, white_bkgd, out);
     ZEST_RETURN_LAUNCH("zest_render_fused_fwd(combine)");

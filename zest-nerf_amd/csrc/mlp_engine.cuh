@@ -63,6 +63,9 @@ constexpr int kChunk = ZEST_CHUNK, kSlots = ZEST_SLOTS, kRingUnits = kChunk * kS
 static_assert(kStreamAlign % kRingUnits == 0, "stream padding must be a multiple of the ring size");
 static_assert(kSlots >= kAhead + 1, "a slot is refilled while the previous chunk may still be read");
 
+#ifndef ZEST_DEFER_DMA
+#define ZEST_DEFER_DMA 0   // 1: weight DMA issued in the row-block epilogues instead of at the rendezvous (see flush())
+#endif
 #ifndef ZEST_ISSUERS
 #define ZEST_ISSUERS 8     // waves of the workgroup that issue the weight DMA (8: every wave its share; 4: waves 0-3,
 #endif                     // one per SIMD, take all of it and their SIMD partners 4-7 none - measured in DESIGN.md section 4)
@@ -238,6 +241,7 @@ struct RingTiles {
 #ifdef ZEST_STAMPS
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #endif
+        flush();
         // all but the youngest (kAhead-1)*kPieces of this wave's DMA pieces have landed
         asm volatile("s_waitcnt vmcnt(%0)" ::"i"((kAhead - 1) * kPieces) : "memory");
 #ifdef ZEST_STAMPS
@@ -251,13 +255,36 @@ struct RingTiles {
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();
 #endif
 #ifndef ZEST_EXPERIMENT_NO_DMA          // timing experiment only
+#if ZEST_DEFER_DMA
+        pending = chunk + kAhead;               // issued by the next flush(): a layer's epilogue
+#else
         issue(chunk + kAhead);
+#endif
 #endif
 #ifdef ZEST_STAMPS
         t_wait += t1 - t0, t_issue += __builtin_amdgcn_s_memtime() - t1;
 #endif
     }
 #endif
+    // ZEST_DEFER_DMA: the refill of the slot a rendezvous frees is not issued at the rendezvous - in the middle
+    // of a run of MFMAs and tile reads, where an LDS-DMA piece holds the wave's issue for 100+ cycles
+    // (MI355X_MICROARCH.md, row 'LDS-DMA piece issue cost') - but at the next row block's epilogue, among plain
+    // VALU instructions.  `pending` is a compile-time constant at every use once the network is unrolled (it is -1
+    // again at the end of a net's stream, so also around the pass loop).  The counted vmcnt of enter_chunk is
+    // unchanged: a refill still pending at the next rendezvous is issued there, in front of the wait.
+    mutable int pending = -1;
+    __device__ __forceinline__ void flush() const {
+#if ZEST_DEFER_DMA
+#ifdef ZEST_STAMPS
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#endif
+        if (pending >= 0) issue(pending);
+        pending = -1;
+#ifdef ZEST_STAMPS
+        t_issue += __builtin_amdgcn_s_memtime() - t1;
+#endif
+#endif
+    }
     __device__ __forceinline__ void touch(int unit) const {
         if (unit % kChunk == 0) enter_chunk(unit / kChunk);
 #ifdef ZEST_RING_FLAGS
@@ -303,6 +330,7 @@ struct RingTiles {
 #endif
             enter_chunk(u / kChunk);
         }
+        flush();
     }
     __device__ __forceinline__ void drain() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
@@ -390,6 +418,26 @@ __device__ __forceinline__ void store_tile(const float (&v)[8], OpArr<N, ep_part
     }
 }
 
+// ReLU of a bf16 operand tile AFTER rounding, on the packed pairs: a negative bf16 is a negative int16, so
+// max(x, 0) per 16-bit half is one v_pk_max_i16 for two values where relu in fp32 costs one v_med3_f32 each.
+// Same bits as relu-then-round (rounding keeps the sign; -0 becomes +0 either way).  The engine's issue port
+// is the contended resource (MI355X_MICROARCH.md, row 'vector-instruction ISSUE cost': a 16x16x32 MFMA leaves
+// room for two plain VALU instructions): this takes 8 of the ~33 VALU instructions of a 256-wide row block away.
+#ifndef ZEST_PACKED_RELU
+#define ZEST_PACKED_RELU 1
+#endif
+typedef __attribute__((ext_vector_type(2))) short s16x2_t;
+__device__ __forceinline__ unsigned relu_bf16x2(unsigned u) {
+    const s16x2_t r = __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, u), s16x2_t{0, 0});
+    return __builtin_bit_cast(unsigned, r);
+}
+template <int N>
+__device__ __forceinline__ void store_tile_relu_bf16(const float (&v)[8], OpArr<N, 1> &op, int k) {
+    const uint4 q = make_uint4(relu_bf16x2(pack_bf16(v[0], v[1])), relu_bf16x2(pack_bf16(v[2], v[3])),
+                               relu_bf16x2(pack_bf16(v[4], v[5])), relu_bf16x2(pack_bf16(v[6], v[7])));
+    op.t[0][k] = __builtin_bit_cast(bf16x8, q);
+}
+
 #ifndef ZEST_PREFETCH
 #define ZEST_PREFETCH 3        // weight tiles kept in flight ahead of the MFMAs that consume them
 #endif
@@ -431,6 +479,8 @@ __device__ __forceinline__ void engine_layer(const Tiles &tiles, int &unit, bool
     constexpr bool X3 = EP == ZEST_PREC_F16X3;
     constexpr int NM = MOD ? 2 * NKF : 0, T = NM + 2 * (NKA + NKB);     // tiles per row block
     static_assert(T >= 1, "empty layer");
+    // a sink wants the activated fp32 values: only the plain inference layer rounds first
+    constexpr bool kPackedRelu = ZEST_PACKED_RELU && RELU && MODE == 0 && EP == ZEST_PREC_BF16 && __is_same(Sink, NoSink);
     auto preload = [&](RowBlockPre<NP> &p, int u0) {            // u0: the row block's header unit
 #pragma unroll
         for (int rt = 0; rt < 2; rt++) {
@@ -503,6 +553,7 @@ __device__ __forceinline__ void engine_layer(const Tiles &tiles, int &unit, bool
         }
         unit = u0 + 1 + NP * T;
         if (jb + 1 < NJB) preload(pre, unit);                   // in flight during the epilogue
+        tiles.flush();
 #pragma unroll
         for (int cb = 0; cb < CB; cb++) {
             float v[8];
@@ -515,10 +566,11 @@ __device__ __forceinline__ void engine_layer(const Tiles &tiles, int &unit, bool
                     if (X3) mv = fmaf(mcorr[i >> 2][cb][i & 3], kLoUnscale, mv);
                     v[i] = v2 ? v[i] + mv : v[i] * mv;
                 }
-                if (RELU) v[i] = relu1<EP>(v[i]);
+                if (RELU && !kPackedRelu) v[i] = relu1<EP>(v[i]);
             }
             if (MODE == 0) {
-                store_tile<EP>(v, out[cb], jb);
+                if constexpr (kPackedRelu) store_tile_relu_bf16(v, out[cb], jb);
+                else store_tile<EP>(v, out[cb], jb);
                 sink(sink_id, jb, cb, v);
             } else if (jb == 0) {
                 keep[cb] = f32x4{v[0], v[1], v[2], v[3]};

@@ -71,21 +71,33 @@ __global__ void nchw_to_nhwc_kernel(const float *__restrict__ in, int N, int C, 
 // Phase 2 walks the voxels 16 at a time with lane = (voxel of the group, channel octet h): a
 // bilinear tap of a voxel is then one 128-byte line read by 4 neighbouring lanes (two 16-byte
 // loads each, one 32-bit offset per tap), where a lane-per-voxel gather touches 64 lines per
-// load instruction and uses 16 bytes of each.  The 4V + 32 output values of the 64 voxels are
-// transposed through LDS (row stride 66 floats) so every output plane receives 256 contiguous
-// bytes, written with streaming stores.  Geometry and transpose tile are separate LDS arrays, so
-// the four groups are independent for the compiler and their loads overlap.
-constexpr int kRowStride = 66;
+// load instruction and uses 16 bytes of each.  The 4V + 32 output values of a voxel leave from the
+// registers of its four lanes with streaming stores: a store instruction writes 64 contiguous bytes
+// (the group's 16 voxels) of four planes, and the workgroup's four groups complete each plane's 256
+// bytes back to back.  (Round 1 transposed them through a 12 KB LDS tile into 256-byte stores; the tile
+// held the CU to 9 one-wave workgroups, and this kernel is bound by issue latency, not by either stream.)
 constexpr int kMaxViews = 8;
+constexpr int kRowStride = 66;      // row stride (floats) of the backward kernel's LDS transpose tile
 
+// Round 1's output path, kept for A/B timing (-DZEST_SWEEP_TILE=1): the 4V + 32 values of the 64 voxels are
+// transposed through a 12 KB LDS tile so that every plane receives one 256-byte store per workgroup.
+#ifndef ZEST_SWEEP_TILE
+#define ZEST_SWEEP_TILE 0
+#endif
+#if ZEST_SWEEP_TILE
+#if ZEST_SWEEP_TILE == 2          // the tile holds 32 voxels: two rounds of transpose + 128-byte stores, half the LDS
+constexpr int kTileStride = 34, kTileIts = 2;
+#else
+constexpr int kTileStride = 66, kTileIts = 4;
+#endif
 template <int VT>                   // VT > 0: compile-time view count (loops unroll)
-__global__ __launch_bounds__(64) void volume_cost_kernel(
+__global__ __launch_bounds__(64) void volume_cost_tile_kernel(
     const float4 *__restrict__ feats, const float4 *__restrict__ imgs, const float *__restrict__ proj,
     const float *__restrict__ depth, int V_rt, int D, int H, int W, int pad, float *__restrict__ img_feat,
     float *__restrict__ in_masks) {
     const int V = VT > 0 ? VT : V_rt;
     constexpr int VM = VT > 0 ? VT : kMaxViews;
-    __shared__ float tile[(4 * VM + kC) * kRowStride];         // [rows][kRowStride]
+    __shared__ float tile[(4 * VM + kC) * kTileStride];         // [rows][kTileStride]
     __shared__ int4 toff[(VM - 1) * 64];                       // bilinear tap offsets / weights per source view
     __shared__ float4 tw[(VM - 1) * 64];
     __shared__ float4 vox[64];          // ref pixel offset (-1: ring, -2: past the end), 1/count, in-frame bit mask
@@ -126,9 +138,11 @@ __global__ __launch_bounds__(64) void volume_cost_kernel(
     // immediate.
     const int v16 = lane >> 2, h = lane & 3;
     const char *fbase = reinterpret_cast<const char *>(feats);
+  for (int round = 0; round < 4 / kTileIts; round++) {
 #pragma unroll
-    for (int it = 0; it < 4; it++) {
-        const int v = it * 16 + v16;
+    for (int it0 = 0; it0 < kTileIts; it0++) {
+        const int it = round * kTileIts + it0;
+        const int v = it * 16 + v16, vt = it0 * 16 + v16;       // voxel of the workgroup / of the tile
         const float4 g = vox[v];
         const int ref_off = __float_as_int(g.x);
         const bool has_ref = ref_off >= 0;
@@ -178,42 +192,207 @@ __global__ __launch_bounds__(64) void volume_cost_kernel(
             bx += __shfl_xor(bx, 1, 64), by += __shfl_xor(by, 1, 64), bz += __shfl_xor(bz, 1, 64);
             bx += __shfl_xor(bx, 2, 64), by += __shfl_xor(by, 2, 64), bz += __shfl_xor(bz, 2, 64);
             if (h == 0) {
-                tile[(3 * i) * kRowStride + v] = bx, tile[(3 * i + 1) * kRowStride + v] = by;
-                tile[(3 * i + 2) * kRowStride + v] = bz;
-                tile[(3 * V + kC + i) * kRowStride + v] = ((__float_as_int(g.z) >> i) & 1) ? 1.0f : 0.0f;
+                tile[(3 * i) * kTileStride + vt] = bx, tile[(3 * i + 1) * kTileStride + vt] = by;
+                tile[(3 * i + 2) * kTileStride + vt] = bz;
+                tile[(3 * V + kC + i) * kTileStride + vt] = ((__float_as_int(g.z) >> i) & 1) ? 1.0f : 0.0f;
             }
         }
         if (h == 0) {
             // the reference leaves channels 0-2 of the padding ring uninitialised (torch.empty); 0 here
             const float4 c0 = imgs[has_ref ? ref_off : 0];
-            tile[0 * kRowStride + v] = has_ref ? c0.x : 0.f, tile[1 * kRowStride + v] = has_ref ? c0.y : 0.f;
-            tile[2 * kRowStride + v] = has_ref ? c0.z : 0.f;
-            tile[(3 * V + kC) * kRowStride + v] = 1.0f;
+            tile[0 * kTileStride + vt] = has_ref ? c0.x : 0.f, tile[1 * kTileStride + vt] = has_ref ? c0.y : 0.f;
+            tile[2 * kTileStride + vt] = has_ref ? c0.z : 0.f;
+            tile[(3 * V + kC) * kTileStride + vt] = 1.0f;
         }
         const float inv = g.y;
-        float *o = tile + (size_t)(3 * V + 8 * h) * kRowStride + v;
+        float *o = tile + (size_t)(3 * V + 8 * h) * kTileStride + vt;
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             float mean = sum[j].x * inv;
-            o[(4 * j) * kRowStride] = sq[j].x * inv - mean * mean;
-            mean = sum[j].y * inv, o[(4 * j + 1) * kRowStride] = sq[j].y * inv - mean * mean;
-            mean = sum[j].z * inv, o[(4 * j + 2) * kRowStride] = sq[j].z * inv - mean * mean;
-            mean = sum[j].w * inv, o[(4 * j + 3) * kRowStride] = sq[j].w * inv - mean * mean;
+            o[(4 * j) * kTileStride] = sq[j].x * inv - mean * mean;
+            mean = sum[j].y * inv, o[(4 * j + 1) * kTileStride] = sq[j].y * inv - mean * mean;
+            mean = sum[j].z * inv, o[(4 * j + 2) * kTileStride] = sq[j].z * inv - mean * mean;
+            mean = sum[j].w * inv, o[(4 * j + 3) * kTileStride] = sq[j].w * inv - mean * mean;
         }
     }
     __syncthreads();
+#if ZEST_SWEEP_TILE == 2
+    {
+        // lanes 0-31 / 32-63 take even / odd rows: one instruction stores 128 bytes of two planes
+        const int vl = lane & 31, rp = lane >> 5;
+        const long long idx = base + round * 32 + vl;
+        if (idx < nvox) {
+            for (int r = rp; r < 4 * V + kC; r += 2) {
+                float *dst = r < 3 * V + kC ? img_feat + (size_t)r * nvox : in_masks + (size_t)(r - 3 * V - kC) * nvox;
+                __builtin_nontemporal_store(tile[r * kTileStride + vl], dst + idx);
+            }
+        }
+    }
+    __syncthreads();
+  }
+}
+#else
     const long long idx = base + lane;
-    if (idx >= nvox) return;
+    if (idx < nvox) {
     for (int r = 0; r < 3 * V + kC; r++) {
-#ifdef ZEST_EXPERIMENT_NO_WRITE        // timing experiment only
-        if (tile[r * kRowStride + lane] == 123456.0f)
-#endif
         // streaming stores: 475 MB of output must not evict the few MB of feature maps from L2
-        __builtin_nontemporal_store(tile[r * kRowStride + lane], &img_feat[(size_t)r * nvox + idx]);
+        __builtin_nontemporal_store(tile[r * kTileStride + lane], &img_feat[(size_t)r * nvox + idx]);
     }
     for (int i = 0; i < V; i++)
-        __builtin_nontemporal_store(tile[(3 * V + kC + i) * kRowStride + lane], &in_masks[(size_t)i * nvox + idx]);
+        __builtin_nontemporal_store(tile[(3 * V + kC + i) * kTileStride + lane], &in_masks[(size_t)i * nvox + idx]);
+    }
+  }
 }
+#endif
+
+#define volume_cost_kernel volume_cost_tile_kernel
+#else
+template <int VT>                   // VT > 0: compile-time view count (loops unroll)
+#ifdef ZEST_SWEEP_WAVES             // occupancy experiment: cap the registers for this many waves per SIMD
+__attribute__((amdgpu_waves_per_eu(ZEST_SWEEP_WAVES, ZEST_SWEEP_WAVES)))
+#endif
+__global__ __launch_bounds__(64) void volume_cost_kernel(
+    const float4 *__restrict__ feats, const float4 *__restrict__ imgs, const float *__restrict__ proj,
+    const float *__restrict__ depth, int V_rt, int D, int H, int W, int pad, float *__restrict__ img_feat,
+    float *__restrict__ in_masks) {
+    const int V = VT > 0 ? VT : V_rt;
+    constexpr int VM = VT > 0 ? VT : kMaxViews;
+    __shared__ int4 toff[(VM - 1) * 64];                       // bilinear tap offsets / weights per source view
+    __shared__ float4 tw[(VM - 1) * 64];
+    __shared__ float4 vox[64];          // ref pixel offset (-1: ring, -2: past the end), 1/count, in-frame bit mask
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+    const long long nvox = (long long)D * Hp * Wp;
+    const int lane = threadIdx.x;
+    const long long base = (long long)blockIdx.x * 64;
+    {   // ---- phase 1: lane = voxel
+        const long long idx = base + lane;
+        const bool live = idx < nvox;
+        // 32-bit index arithmetic (the host checks nvox < 2^31)
+        const unsigned ic = (unsigned)(live ? idx : nvox - 1);
+        const unsigned row = ic / (unsigned)Wp;
+        const int x = (int)(ic - row * (unsigned)Wp), d = (int)(row / (unsigned)Hp), y = (int)(row - (unsigned)d * (unsigned)Hp);
+        const int xr = x - pad, yr = y - pad;
+        const bool inside = (unsigned)xr < (unsigned)W && (unsigned)yr < (unsigned)H;
+        const float dep = depth[d];
+        float count = 1.0f;
+        int in_frame = 1;
+#pragma unroll
+        for (int i = 1; i < V; i++) {
+            float gx, gy;
+            project(proj + 12 * (i - 1), (float)xr, (float)yr, dep, H, W, gx, gy);
+            const bool m = gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f;
+            count += m ? 1.0f : 0.0f, in_frame |= m ? (1 << i) : 0;
+            const Tap4 t = taps(gx, gy, H, W);
+            toff[(i - 1) * 64 + lane] = make_int4(t.off[0], t.off[1], t.off[2], t.off[3]);
+            tw[(i - 1) * 64 + lane] = make_float4(t.w[0], t.w[1], t.w[2], t.w[3]);
+        }
+        vox[lane] = make_float4(__int_as_float(live && inside ? yr * W + xr : -1), 1.0f / count,
+                                __int_as_float(in_frame), 0.0f);
+    }
+    __syncthreads();
+    // ---- phase 2: lane = (voxel of a group of 16, channel octet h).  Branch-free, so the four
+    // groups form one basic block and the compiler keeps their loads in flight together (voxels
+    // past the end of the volume compute on clamped addresses and are dropped at the final
+    // store).  One 32-bit byte offset per tap; the octet's two 16-byte halves differ by an
+    // immediate.
+    const int v16 = lane >> 2, h = lane & 3;
+    const char *fbase = reinterpret_cast<const char *>(feats);
+#ifndef ZEST_SWEEP_UNROLL
+#define ZEST_SWEEP_UNROLL 4         // groups of 16 voxels whose gathers are in flight together
+#endif
+#pragma unroll ZEST_SWEEP_UNROLL
+    for (int it = 0; it < 4; it++) {
+        const int v = it * 16 + v16;
+        const long long idx = base + v;
+        const bool live = idx < nvox;
+        const float4 g = vox[v];
+        const int ref_off = __float_as_int(g.x);
+        const bool has_ref = ref_off >= 0;
+        // reference view: its own feature map, zero in the padding ring
+        float4 sum[2], sq[2];
+        {
+            const unsigned bo = (unsigned)(has_ref ? ref_off : 0) * 128u + (unsigned)h * 32u;
+            const float4 r0 = *reinterpret_cast<const float4 *>(fbase + bo);
+            const float4 r1 = *reinterpret_cast<const float4 *>(fbase + bo + 16);
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            sum[0] = has_ref ? r0 : z4, sum[1] = has_ref ? r1 : z4;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+            sq[j] = make_float4(sum[j].x * sum[j].x, sum[j].y * sum[j].y, sum[j].z * sum[j].z, sum[j].w * sum[j].w);
+#pragma unroll
+        for (int i = 1; i < V; i++) {
+            const int4 o4 = toff[(i - 1) * 64 + v];
+            const float4 w4 = tw[(i - 1) * 64 + v];
+            const unsigned view_b = (unsigned)i * (unsigned)(H * W) * 128u + (unsigned)h * 32u;
+            const unsigned b0 = view_b + (unsigned)o4.x * 128u, b1 = view_b + (unsigned)o4.y * 128u,
+                           b2 = view_b + (unsigned)o4.z * 128u, b3 = view_b + (unsigned)o4.w * 128u;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+#ifdef ZEST_EXPERIMENT_NO_GATHER       // timing experiment only
+                const float4 t0 = w4, t1 = w4, t2 = w4, t3 = w4;
+#else
+                const float4 t0 = *reinterpret_cast<const float4 *>(fbase + b0 + 16 * j),
+                             t1 = *reinterpret_cast<const float4 *>(fbase + b1 + 16 * j),
+                             t2 = *reinterpret_cast<const float4 *>(fbase + b2 + 16 * j),
+                             t3 = *reinterpret_cast<const float4 *>(fbase + b3 + 16 * j);
+#endif
+                float4 a;
+                a.x = fmaf(w4.w, t3.x, fmaf(w4.z, t2.x, fmaf(w4.y, t1.x, w4.x * t0.x)));
+                a.y = fmaf(w4.w, t3.y, fmaf(w4.z, t2.y, fmaf(w4.y, t1.y, w4.x * t0.y)));
+                a.z = fmaf(w4.w, t3.z, fmaf(w4.z, t2.z, fmaf(w4.y, t1.z, w4.x * t0.z)));
+                a.w = fmaf(w4.w, t3.w, fmaf(w4.z, t2.w, fmaf(w4.y, t1.w, w4.x * t0.w)));
+                sum[j].x += a.x, sum[j].y += a.y, sum[j].z += a.z, sum[j].w += a.w;
+                sq[j].x = fmaf(a.x, a.x, sq[j].x), sq[j].y = fmaf(a.y, a.y, sq[j].y);
+                sq[j].z = fmaf(a.z, a.z, sq[j].z), sq[j].w = fmaf(a.w, a.w, sq[j].w);
+            }
+            // image of this view: lane h takes tap h, two quad shuffles add the four up (every lane of the quad
+            // then holds the sums); lane h < 3 stores colour channel h, lane 3 the in-frame mask
+            const int off = h == 0 ? o4.x : h == 1 ? o4.y : h == 2 ? o4.z : o4.w;
+            const float wgt = h == 0 ? w4.x : h == 1 ? w4.y : h == 2 ? w4.z : w4.w;
+            const float4 tv = imgs[(size_t)i * H * W + off];
+            float bx = wgt * tv.x, by = wgt * tv.y, bz = wgt * tv.z;
+            bx += __shfl_xor(bx, 1, 64), by += __shfl_xor(by, 1, 64), bz += __shfl_xor(bz, 1, 64);
+            bx += __shfl_xor(bx, 2, 64), by += __shfl_xor(by, 2, 64), bz += __shfl_xor(bz, 2, 64);
+            const float m = ((__float_as_int(g.z) >> i) & 1) ? 1.0f : 0.0f;
+            if (live)
+                __builtin_nontemporal_store(h == 0 ? bx : h == 1 ? by : h == 2 ? bz : m,
+                                            (h < 3 ? img_feat + (size_t)(3 * i + h) * nvox : in_masks + (size_t)i * nvox) + idx);
+        }
+        {
+            // reference view: its own colours (the reference leaves channels 0-2 of the padding ring
+            // uninitialised (torch.empty); 0 here) and an all-ones mask
+            const float4 c0 = imgs[has_ref ? ref_off : 0];
+            const float val = !has_ref && h < 3 ? 0.f : (h == 0 ? c0.x : h == 1 ? c0.y : h == 2 ? c0.z : 1.0f);
+            if (live) __builtin_nontemporal_store(val, (h < 3 ? img_feat + (size_t)h * nvox : in_masks) + idx);
+        }
+        // variance of the 8 channels of this lane's octet, straight from registers: one store instruction
+        // writes 64 contiguous bytes (16 voxels) of four planes, and the four groups of a workgroup complete
+        // each plane's 256 bytes back to back (the lines merge in L2 before they leave for HBM).  No LDS
+        // transpose tile: the workgroup keeps 5 KB of LDS instead of 17, which was what limited the CU to 9 waves.
+        const float inv = g.y;
+        float *o = img_feat + (size_t)(3 * V + 8 * h) * nvox + idx;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const float m0 = sum[j].x * inv, m1 = sum[j].y * inv, m2 = sum[j].z * inv, m3 = sum[j].w * inv;
+            const float v0 = sq[j].x * inv - m0 * m0, v1 = sq[j].y * inv - m1 * m1;
+            const float v2 = sq[j].z * inv - m2 * m2, v3 = sq[j].w * inv - m3 * m3;
+            if (live) {
+#ifdef ZEST_EXPERIMENT_NO_WRITE        // timing experiment only
+                if (v0 == 123456.0f)
+#endif
+                {
+                    __builtin_nontemporal_store(v0, o + (size_t)(4 * j) * nvox);
+                    __builtin_nontemporal_store(v1, o + (size_t)(4 * j + 1) * nvox);
+                    __builtin_nontemporal_store(v2, o + (size_t)(4 * j + 2) * nvox);
+                    __builtin_nontemporal_store(v3, o + (size_t)(4 * j + 3) * nvox);
+                }
+            }
+        }
+    }
+}
+
+#endif
 
 // src [C,H,W]; grid_in (optional) [D,Hp,Wp,2] normalised positions to reuse; outputs
 // warped [C,D,Hp,Wp] and (when computed here) grid_out [D,Hp,Wp,2]

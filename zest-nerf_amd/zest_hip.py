@@ -117,7 +117,7 @@ _SIGS = {
                                    _f, _i, _i, _vp, _vp, _vp]),
     "zest_render_fused_workspace": (_sz, [_i, _i]),
     "zest_render_fused_set_passes": (_i, [_i]),
-    "zest_render_fused_pass_shape": (_i, [_i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
+    "zest_render_fused_pass_shape": (_i, [_i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
 }
 
 _lib = None
@@ -668,17 +668,19 @@ def make_view_set(vol_cl=None, imgs_cl=None, w2cs=None, intrinsics=None):
 
 
 def set_fused_passes(shape):
-    """None / "auto": pass shape chosen per launch; "dense" | "aligned": forced (tests, measurements)."""
-    _check(lib().zest_render_fused_set_passes({None: 0, "auto": 0, "dense": 1, "aligned": 2}[shape]),
+    """None / "auto": pass shape chosen per launch; "dense" | "ranges": forced (tests, measurements)."""
+    _check(lib().zest_render_fused_set_passes({None: 0, "auto": 0, "dense": 1, "ranges": 2}[shape]),
            "zest_render_fused_set_passes")
 
 
 def fused_pass_shape(R, S, precision=PREC_BF16, cus=256):
-    """-> (rays_per_pass, n_pass) the fused renderer takes for this batch shape (rays_per_pass 0 = dense passes)."""
-    rpp, n = _i(0), _i(0)
-    _check(lib().zest_render_fused_pass_shape(int(R), int(S), int(precision), int(cus), C.byref(rpp), C.byref(n)),
-           "zest_render_fused_pass_shape")
-    return rpp.value, n.value
+    """-> (ray_ranges, n_wg, rounds) the fused renderer takes for this batch shape: ray_ranges 1 = a range of
+    whole rays per workgroup (rays finished in the kernel), 0 = dense block shares + combine launch; n_wg =
+    workgroups launched, rounds = passes of the busiest workgroup."""
+    rr, n, rounds = _i(0), _i(0), _i(0)
+    _check(lib().zest_render_fused_pass_shape(int(R), int(S), int(precision), int(cus), C.byref(rr), C.byref(n),
+                                              C.byref(rounds)), "zest_render_fused_pass_shape")
+    return rr.value, n.value, rounds.value
 
 
 def render_fused(ndc, pts, z, rays_dir, desc_s, packed_s, views_s, desc_d=None, packed_d=None,

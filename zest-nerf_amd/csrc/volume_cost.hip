@@ -17,6 +17,14 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kC = 32;               // feature channels of FeatureNet's top level
 
+// sum over the four lanes of a quad, result on all four: two DPP quad permutes ([1,0,3,2], [2,3,0,1]) instead of
+// the two LDS-crossbar shuffles (ds_bpermute) __shfl_xor compiles to
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+    return v;
+}
+
 struct Tap4 {                        // bilinear taps, zero padding, align_corners (grid_sample)
     int off[4];                      // pixel offsets y * W + x (clamped when the weight is 0)
     float w[4];
@@ -79,10 +87,13 @@ __global__ void nchw_to_nhwc_kernel(const float *__restrict__ in, int N, int C, 
 constexpr int kMaxViews = 8;
 constexpr int kRowStride = 66;      // row stride (floats) of the backward kernel's LDS transpose tile
 
-// Round 1's output path, kept for A/B timing (-DZEST_SWEEP_TILE=1): the 4V + 32 values of the 64 voxels are
-// transposed through a 12 KB LDS tile so that every plane receives one 256-byte store per workgroup.
+// Output path.  ZEST_SWEEP_TILE=1 (default): the 4V + 32 values of the 64 voxels are transposed through a 12 KB LDS
+// tile so that every plane receives one 256-byte store per workgroup.  =2: a tile of 32 voxels, two rounds of
+// 128-byte stores, 14 instead of 9 workgroups per CU.  =0: no tile, 64-byte stores straight from the registers
+// of phase 2, 16 workgroups per CU.  Measured on one MI355X (NSFF geometry, same process, two repeats each):
+// 183-186 us / 191-198 us / 205-208 us: the width of the stores matters more than the waves in flight.
 #ifndef ZEST_SWEEP_TILE
-#define ZEST_SWEEP_TILE 0
+#define ZEST_SWEEP_TILE 1
 #endif
 #if ZEST_SWEEP_TILE
 #if ZEST_SWEEP_TILE == 2          // the tile holds 32 voxels: two rounds of transpose + 128-byte stores, half the LDS
@@ -189,8 +200,7 @@ __global__ __launch_bounds__(64) void volume_cost_tile_kernel(
             const float wgt = h == 0 ? w4.x : h == 1 ? w4.y : h == 2 ? w4.z : w4.w;
             const float4 tv = imgs[(size_t)i * H * W + off];
             float bx = wgt * tv.x, by = wgt * tv.y, bz = wgt * tv.z;
-            bx += __shfl_xor(bx, 1, 64), by += __shfl_xor(by, 1, 64), bz += __shfl_xor(bz, 1, 64);
-            bx += __shfl_xor(bx, 2, 64), by += __shfl_xor(by, 2, 64), bz += __shfl_xor(bz, 2, 64);
+            bx = quad_sum(bx), by = quad_sum(by), bz = quad_sum(bz);
             if (h == 0) {
                 tile[(3 * i) * kTileStride + vt] = bx, tile[(3 * i + 1) * kTileStride + vt] = by;
                 tile[(3 * i + 2) * kTileStride + vt] = bz;
@@ -352,8 +362,7 @@ __global__ __launch_bounds__(64) void volume_cost_kernel(
             const float wgt = h == 0 ? w4.x : h == 1 ? w4.y : h == 2 ? w4.z : w4.w;
             const float4 tv = imgs[(size_t)i * H * W + off];
             float bx = wgt * tv.x, by = wgt * tv.y, bz = wgt * tv.z;
-            bx += __shfl_xor(bx, 1, 64), by += __shfl_xor(by, 1, 64), bz += __shfl_xor(bz, 1, 64);
-            bx += __shfl_xor(bx, 2, 64), by += __shfl_xor(by, 2, 64), bz += __shfl_xor(bz, 2, 64);
+            bx = quad_sum(bx), by = quad_sum(by), bz = quad_sum(bz);
             const float m = ((__float_as_int(g.z) >> i) & 1) ? 1.0f : 0.0f;
             if (live)
                 __builtin_nontemporal_store(h == 0 ? bx : h == 1 ? by : h == 2 ? bz : m,

@@ -397,7 +397,7 @@ def main():
                        "backend": ("rccl" if dist is not None else "none")},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                          "frac": ach / peak, "traffic": pmc_traffic(a.workload, a.mode),
-                         "kernel": "fused_blocks_kernel (rays finished in-kernel when a pass holds whole rays; else + fused_combine_kernel)",
+                         "kernel": "fused_blocks_kernel (one launch: a range of whole rays per workgroup, rays finished in the kernel)",
                          "kernel_ms": k_ms, "flop_per_sample": fps,
                          "note": "achieved = algorithmic MLP FLOPs of one launch / HIP-event time of the "
                                  "launch on its stream; traffic = HBM bytes per launch from the "

@@ -427,12 +427,18 @@ __global__ __launch_bounds__(kWaves * 64, kWaves / 4) void train16_dw_kernel(
         return is_out ? grad[(((size_t)b * kGradTiles + job.out_tile0 + kt) * CB + cb) * 64 + lane]
                       : stash[(((size_t)b * kStashTiles + job.in_tile0 + kt) * CB + cb) * 64 + lane];
     };
-    uint4 pre[4], pre2[4];                 // tiles of block b and of block b + 1 (requested two blocks ahead of their use)
+    // tiles of blocks b .. b + kDwAhead - 1: requested kDwAhead blocks ahead of their use (HBM latency under the
+    // load of 255 workgroups streaming is several microseconds; a block is ~2 us of work)
+#ifndef ZEST_DW_AHEAD
+#define ZEST_DW_AHEAD 2
+#endif
+    constexpr int kDwAhead = ZEST_DW_AHEAD;
+    uint4 pre[kDwAhead][4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        if (b0 < b1 && wave + 8 * i < items) pre[i] = fetch_item(b0, wave + 8 * i);
-        if (b0 + 1 < b1 && wave + 8 * i < items) pre2[i] = fetch_item(b0 + 1, wave + 8 * i);
-    }
+    for (int d = 0; d < kDwAhead; d++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (b0 + d < b1 && wave + 8 * i < items) pre[d][i] = fetch_item(b0 + d, wave + 8 * i);
     for (long long b = b0; b < b1; b++) {
         const int buf = (int)((b - b0) & 1);
         char *im_out = img[buf][0], *im_in = img[buf][1];
@@ -444,7 +450,7 @@ __global__ __launch_bounds__(kWaves * 64, kWaves / 4) void train16_dw_kernel(
             const int t = it / CB, cb = it % CB;
             const bool is_out = t < n_out;
             const int kt = is_out ? t : t - n_out;
-            *reinterpret_cast<uint4 *>((is_out ? im_out : im_in) + (16 * cb + col) * kImgStride + kt * 64 + grp * 16) = pre[i];
+            *reinterpret_cast<uint4 *>((is_out ? im_out : im_in) + (16 * cb + col) * kImgStride + kt * 64 + grp * 16) = pre[0][i];
         }
         if (job.in_kind != 0 && wave < CB) {            // operands rebuilt from the rows of x: one column block per wave
             const int cb = wave;
@@ -477,8 +483,9 @@ __global__ __launch_bounds__(kWaves * 64, kWaves / 4) void train16_dw_kernel(
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            pre[i] = pre2[i];
-            if (b + 2 < b1 && wave + 8 * i < items) pre2[i] = fetch_item(b + 2, wave + 8 * i);
+#pragma unroll
+            for (int d = 0; d + 1 < kDwAhead; d++) pre[d][i] = pre[d + 1][i];
+            if (b + kDwAhead < b1 && wave + 8 * i < items) pre[kDwAhead - 1][i] = fetch_item(b + kDwAhead, wave + 8 * i);
         }
         if (wave < n_out) {
             const unsigned a_out = img0 + (unsigned)(buf * 2) * kImgBytes, a_in = a_out + kImgBytes;

@@ -381,16 +381,13 @@ class FeatureNet(nn.Module):
         return torch.nn.functional.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True) + y
 
     def forward(self, x):
-        activ_maps = []
-        x = self.conv0(x)
-        activ_maps.append(x)
-        x = self.conv1(x)
-        activ_maps.append(x)
-        x = self.conv2(x)
-        activ_maps.append(x)
-        x = self.toplayer(x)
-        activ_maps.append(x)
-        return x, activ_maps
+        """-> (top-level features, the output of every stage).  Only the first element is on the path; the
+        list keeps the reference's call shape (its vis_test dumps read it, networks.py:1162-1181)."""
+        stages = []
+        for stage in (self.conv0, self.conv1, self.conv2, self.toplayer):
+            x = stage(x)
+            stages.append(x)
+        return x, stages
 
 
 class CostRegNet(nn.Module):
@@ -410,20 +407,19 @@ class CostRegNet(nn.Module):
         self.conv7, self.conv9, self.conv11 = up(64, 32), up(32, 16), up(16, 8)
 
     def forward(self, x):
-        activ_maps = []
-        conv0 = self.conv0(x)
-        conv2 = self.conv2(self.conv1(conv0))
-        conv4 = self.conv4(self.conv3(conv2))
-        activ_maps += [conv0, conv2, conv4]
-        x = self.conv6(self.conv5(conv4))
-        activ_maps.append(x)
-        x = conv4 + self.conv7(x)
-        activ_maps.append(x)
-        x = conv2 + self.conv9(x)
-        activ_maps.append(x)
-        x = conv0 + self.conv11(x)
-        activ_maps.append(x)
-        return x, activ_maps
+        """-> (encoding volume, the output of every level: three on the way down, the bottom, three on the way up).
+        Only the first element is on the path (the list: reference call shape, networks.py:1213-1230)."""
+        skips = []
+        for level in ((self.conv0,), (self.conv1, self.conv2), (self.conv3, self.conv4)):
+            for conv in level:
+                x = conv(x)
+            skips.append(x)
+        x = self.conv6(self.conv5(x))
+        levels = skips + [x]
+        for up, skip in zip((self.conv7, self.conv9, self.conv11), reversed(skips)):
+            x = skip + up(x)
+            levels.append(x)
+        return x, levels
 
 
 class MVSNet(nn.Module):

@@ -11,6 +11,9 @@
  *
  * All tensors are dense row-major fp32 unless stated; R = rays, S = samples per ray,
  * M = R*S flattened samples, V = source views.  Inputs are never written.
+ * An empty batch (R == 0 or M == 0) is a successful no-op for every per-ray / per-sample
+ * entry point, whatever the pointers (an empty tensor has no storage); every other
+ * argument the kernels do not cover is refused with a message, before any launch.
  * INTEGRATION.md shows the ctypes binding (zest-nerf_amd/zest_hip.py) a maintainer of
  * the reference would add.
  */

@@ -54,6 +54,23 @@ def test_fused_equals_per_op_path_at_full_size(hip, name):
     assert (acc >= -1e-5).all() and (acc <= 1 + 1e-4).all()
 
 
+@pytest.mark.parametrize("rays", [None, 512])          # BASELINE configs[3]: the full batch on one GPU, the 1-of-8 shard
+def test_configs3_ray_ranges_equal_the_dense_shape_bit_for_bit(hip, rays):
+    """4096 x 192 (6 blocks per ray): the default pass shape - a range of whole rays per workgroup, rays that
+    straddle two passes carried in LDS, waves without a block in the shard's second pass - finishes every ray in
+    the kernel and gives the maps of the dense shape (block records in HBM + combine launch) bit for bit."""
+    import zest_hip
+    d = _workload("zest_val_4096x192", rays=rays)
+    assert zest_hip.fused_pass_shape(d.R, d.S)[0] == 1
+    outs = {}
+    for shape in ("dense", "ranges", None):
+        zest_hip.set_fused_passes(shape)
+        outs[shape] = _maps(d)["zest_packed_maps"].clone()
+    zest_hip.set_fused_passes(None)
+    assert torch.isfinite(outs[None]).all()
+    assert torch.equal(outs["dense"], outs["ranges"]) and torch.equal(outs["dense"], outs[None])
+
+
 def test_fused_ray_permutation_and_sharding_invariance(hip):
     """Rays are independent units: permuting the batch permutes the maps bit for bit, and rendering
     two halves separately gives the rows of the full render (the multi-GPU sharding argument)."""

@@ -27,3 +27,8 @@ for wl in $wls; do
   echo "$n done: $(tail -1 $out/${tag}_${n}_bench_under_rocprofv3.json | cut -c1-200)"
  done
 done
+# the exact default bench command (all modes + CPU baseline leg), kernel trace only
+d=/tmp/prof_default; rm -rf $d
+rocprofv3 --kernel-trace --stats --output-format csv -d $d -o ks -- python3 $R/bench.py > $out/${tag}_bench_default_under_rocprofv3.json 2> $out/default_ks.err
+cp $(find $d -name "*kernel_stats.csv" | head -1) $out/${tag}_bench_default_kernel_stats.csv
+echo "default bench done: $(tail -1 $out/${tag}_bench_default_under_rocprofv3.json | cut -c1-160)"

@@ -159,6 +159,7 @@ extern "C" int zest_composite_fwd(const float *raw, const float *z, const float 
                                   const float *noise, float noise_std, int white_bkgd, int R, int S,
                                   float *rgb_map, float *depth_map, float *acc_map, float *disp_map,
                                   float *weights, float *alpha, void *stream) {
+    if (R == 0) return 0;                       // an empty batch is a no-op (its tensors have no storage)
     ZEST_CHECK_ARG(raw && z && (rays_dir || dists), "zest_composite_fwd: raw, z and rays_dir (or dists) are required");
     ZEST_CHECK_ARG(R >= 0 && S >= 1, "zest_composite_fwd: bad shape R=%d S=%d", R, S);
     ZEST_CHECK_ARG(((uintptr_t)raw & 15) == 0, "zest_composite_fwd: raw must be 16-byte aligned");
@@ -176,6 +177,7 @@ extern "C" int zest_composite_blend_fwd(const float *raw_dy, const float *raw_st
                                         float *rgb_map, float *depth_map, float *rgb_map_fg,
                                         float *depth_map_fg, float *weights_fg, float *weights_dy,
                                         float *weights_dd_sum, void *stream) {
+    if (R == 0) return 0;                       // an empty batch is a no-op (its tensors have no storage)
     ZEST_CHECK_ARG(raw_dy && raw_st && blend && z && (rays_dir || dists),
                    "zest_composite_blend_fwd: raw_dy, raw_st, blend, z, rays_dir (or dists) are required");
     ZEST_CHECK_ARG(R >= 0 && S >= 1, "zest_composite_blend_fwd: bad shape R=%d S=%d", R, S);
@@ -192,6 +194,7 @@ extern "C" int zest_composite_blend_fwd(const float *raw_dy, const float *raw_st
 
 extern "C" int zest_weighted_complement_sum(const float *w, const float *p, int R, int S,
                                             float *out, void *stream) {
+    if (R == 0) return 0;                       // an empty batch is a no-op (its tensors have no storage)
     ZEST_CHECK_ARG(w && p && out, "zest_weighted_complement_sum: null pointer");
     ZEST_CHECK_ARG(R >= 0 && S >= 1, "zest_weighted_complement_sum: bad shape R=%d S=%d", R, S);
     if (R == 0) return 0;

@@ -217,6 +217,7 @@ extern "C" int zest_composite_bwd(const float *raw, const float *z, const float 
                                   const float *noise, float noise_std, int white_bkgd, int R, int S,
                                   const float *g_rgb_map, const float *g_depth_map, const float *g_acc_map,
                                   const float *g_weights, float *g_raw, void *stream) {
+    if (R == 0) return 0;                       // an empty batch is a no-op (its tensors have no storage)
     ZEST_CHECK_ARG(raw && z && (rays_dir || dists) && g_raw, "zest_composite_bwd: raw, z, rays_dir (or dists), g_raw required");
     ZEST_CHECK_ARG(R >= 0 && S >= 1 && S <= 64 * kMaxChunks, "zest_composite_bwd: bad shape R=%d S=%d", R, S);
     ZEST_CHECK_ARG((((uintptr_t)raw | (uintptr_t)g_raw) & 15) == 0, "zest_composite_bwd: 16-byte alignment");
@@ -235,6 +236,7 @@ extern "C" int zest_composite_blend_bwd(const float *raw_dy, const float *raw_st
                                         const float *g_depth_map_fg, const float *g_weights_fg,
                                         const float *g_weights_dy, float *g_raw_dy, float *g_raw_st,
                                         float *g_blend, void *stream) {
+    if (R == 0) return 0;                       // an empty batch is a no-op (its tensors have no storage)
     ZEST_CHECK_ARG(raw_dy && raw_st && blend && z && (rays_dir || dists) && g_raw_dy && g_raw_st && g_blend,
                    "zest_composite_blend_bwd: null argument");
     ZEST_CHECK_ARG(R >= 0 && S >= 1 && S <= 64 * kMaxChunks, "zest_composite_blend_bwd: bad shape");

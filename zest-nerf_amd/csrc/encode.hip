@@ -229,6 +229,7 @@ inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 extern "C" int zest_encode_bwd(const float *g_x, const float *ndc, int R, int S, int has_time, float t,
                                const float *vol_cl, int D, int Hv, int Wv, int V, float *g_ndc,
                                float *g_vol_cl, void *stream) {
+    if (R == 0) return 0;                       // an empty batch is a no-op (its tensors have no storage)
     ZEST_CHECK_ARG(g_x && ndc && g_ndc, "zest_encode_bwd: g_x, ndc and g_ndc are required");
     ZEST_CHECK_ARG(R >= 0 && S >= 1, "zest_encode_bwd: bad shape");
     ZEST_CHECK_ARG(!vol_cl || (aligned16(vol_cl) && D >= 1 && Hv >= 1 && Wv >= 1 && V >= 1),
@@ -251,6 +252,7 @@ extern "C" int zest_volume_from_cl(const float *vol_cl, int D, int H, int W, flo
 }
 
 extern "C" int zest_embed_fwd(const float *x, int M, int C, int L, float *y, void *stream) {
+    if (M == 0) return 0;                       // an empty batch is a no-op (its tensors have no storage)
     ZEST_CHECK_ARG(x && y, "zest_embed_fwd: null pointer");
     ZEST_CHECK_ARG(M >= 0 && C >= 1 && L >= 0 && L <= 16, "zest_embed_fwd: bad shape M=%d C=%d L=%d",
                    M, C, L);
@@ -283,6 +285,7 @@ extern "C" int zest_images_to_cl(const float *imgs, int V, int H, int W, float *
 
 extern "C" int zest_volume_lookup_fwd(const float *vol_cl, int D, int H, int W, const float *ndc,
                                       int M, float *out, void *stream) {
+    if (M == 0) return 0;                       // an empty batch is a no-op (its tensors have no storage)
     ZEST_CHECK_ARG(vol_cl && ndc && out && aligned16(vol_cl) && aligned16(out),
                    "zest_volume_lookup_fwd: bad pointer");
     ZEST_CHECK_ARG(D >= 1 && H >= 1 && W >= 1 && M >= 0, "zest_volume_lookup_fwd: bad shape");
@@ -295,6 +298,7 @@ extern "C" int zest_volume_lookup_fwd(const float *vol_cl, int D, int H, int W, 
 extern "C" int zest_color_lookup_fwd(const float *imgs_cl, int V, int H, int W, const float *w2cs,
                                      const float *intrinsics, const float *pts, int M, float *out,
                                      void *stream) {
+    if (M == 0) return 0;                       // an empty batch is a no-op (its tensors have no storage)
     ZEST_CHECK_ARG(imgs_cl && w2cs && intrinsics && pts && out && aligned16(imgs_cl) &&
                        aligned16(out), "zest_color_lookup_fwd: bad pointer");
     ZEST_CHECK_ARG(V >= 1 && H >= 2 && W >= 2 && M >= 0, "zest_color_lookup_fwd: bad shape");
@@ -309,6 +313,7 @@ extern "C" int zest_encode_fwd(const float *ndc, const float *pts, const float *
                                int S, int has_time, float t, const float *vol_cl, int D, int Hv,
                                int Wv, const float *imgs_cl, int V, int H, int W,
                                const float *w2cs, const float *intrinsics, float *x, void *stream) {
+    if (R == 0) return 0;                       // an empty batch is a no-op (its tensors have no storage)
     ZEST_CHECK_ARG(ndc && rays_dir && x, "zest_encode_fwd: ndc, rays_dir and x are required");
     ZEST_CHECK_ARG(R >= 0 && S >= 1, "zest_encode_fwd: bad shape R=%d S=%d", R, S);
     if (vol_cl) {

@@ -77,7 +77,12 @@ struct RayState {
         o[0] = make_float4(s[0] + bg, s[1] + bg, s[2] + bg, s[3]);
         o[1] = make_float4(s[4], bl[0], bl[1], bl[2]);
         o[2] = make_float4(bl[3], fg[0], fg[1], fg[2]);
-        o[3] = make_float4(fg[3], bl[4], 0.f, 0.f);
+        // (the zero of the two reserved columns is made opaque here: as a plain constant hipcc materialises the
+        // pair once at kernel entry, finds no register for it across the unrolled network and spills it - 1 MiB
+        // of scratch write-back per launch for two zeros)
+        float zero = 0.f;
+        asm volatile("" : "+v"(zero));
+        o[3] = make_float4(fg[3], bl[4], zero, zero);
     }
     // the open ray of a workgroup between two of its passes (kCarryFloats floats in LDS)
     __device__ __forceinline__ void save(float *c) const {

@@ -120,6 +120,7 @@ extern "C" int zest_render_fused_fwd(const float *ndc, const float *pts, const f
                                      const zest_view_set *views_dynamic, float frame_idx,
                                      int precision, int white_bkgd, void *workspace, float *out,
                                      void *stream) {
+    if (R == 0) return 0;                       // an empty batch is a no-op (its tensors have no storage)
     ZEST_CHECK_ARG(ndc && z && rays_dir && out && workspace,
                    "zest_render_fused_fwd: ndc, z, rays_dir, workspace, out required");
     ZEST_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "zest_render_fused_fwd: workspace must be 16-byte aligned");

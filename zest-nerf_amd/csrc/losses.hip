@@ -135,6 +135,7 @@ __global__ __launch_bounds__(kWaves * 64) void project_rays_bwd_kernel(
 
 extern "C" int zest_distortion_fwd(const float *weights, const float *t_vals, int t_rows, int R, int S,
                                    float *loss_ray, float *grad_w, void *stream) {
+    if (R == 0) return 0;                       // an empty batch is a no-op (its tensors have no storage)
     ZEST_CHECK_ARG(weights && t_vals && loss_ray, "zest_distortion_fwd: null pointer");
     ZEST_CHECK_ARG(R >= 0 && S >= 2 && S <= kMaxS + 1, "zest_distortion_fwd: bad shape R=%d S=%d (S <= %d)", R, S, kMaxS + 1);
     ZEST_CHECK_ARG(t_rows == 1 || t_rows == R, "zest_distortion_fwd: t_vals has %d rows, expected 1 or %d", t_rows, R);
@@ -146,6 +147,7 @@ extern "C" int zest_distortion_fwd(const float *weights, const float *t_vals, in
 
 extern "C" int zest_project_rays_fwd(const float *weights, const float *pts, const float *w2c, int H, int W,
                                      float focal, int R, int S, float *out, void *stream) {
+    if (R == 0) return 0;                       // an empty batch is a no-op (its tensors have no storage)
     ZEST_CHECK_ARG(weights && pts && w2c && out, "zest_project_rays_fwd: null pointer");
     ZEST_CHECK_ARG(R >= 0 && S >= 1, "zest_project_rays_fwd: bad shape R=%d S=%d", R, S);
     if (R == 0) return 0;
@@ -157,6 +159,7 @@ extern "C" int zest_project_rays_fwd(const float *weights, const float *pts, con
 extern "C" int zest_project_rays_bwd(const float *weights, const float *pts, const float *w2c, int H, int W,
                                      float focal, const float *grad_out, int R, int S, float *d_weights,
                                      float *d_pts, void *stream) {
+    if (R == 0) return 0;                       // an empty batch is a no-op (its tensors have no storage)
     ZEST_CHECK_ARG(weights && pts && w2c && grad_out && (d_weights || d_pts), "zest_project_rays_bwd: null pointer");
     ZEST_CHECK_ARG(R >= 0 && S >= 1, "zest_project_rays_bwd: bad shape R=%d S=%d", R, S);
     if (R == 0) return 0;

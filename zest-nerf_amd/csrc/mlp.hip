@@ -317,6 +317,7 @@ extern "C" int zest_mlp_pack(const zest_mlp_desc *desc, int precision, const flo
 
 extern "C" int zest_mlp_fwd(const zest_mlp_desc *desc, int precision, const void *packed,
                             const float *x, int M, float *out, void *stream) {
+    if (M == 0) return 0;                       // an empty batch is a no-op (its tensors have no storage)
     ZEST_CHECK_ARG(desc && packed && x && out, "zest_mlp_fwd: null argument");
     ZEST_CHECK_ARG(M >= 0, "zest_mlp_fwd: M=%d", M);
     DevPlan *dp = get_plan(*desc, precision, order_for(precision), false);

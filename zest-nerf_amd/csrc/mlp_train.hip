@@ -256,6 +256,7 @@ extern "C" size_t zest_mlp_train_workspace_floats(const zest_mlp_desc *desc, int
 
 extern "C" int zest_mlp_train_fwd(const zest_mlp_desc *desc, const float *const *params, const float *x,
                                   int M, float *saved, float *workspace, float *out, void *stream) {
+    if (M == 0) return 0;                       // an empty batch is a no-op (its tensors have no storage)
     ZEST_CHECK_ARG(desc && params && x && saved && workspace && out && M > 0, "zest_mlp_train_fwd: bad argument");
     ZEST_CHECK_ARG(desc->net_type == 0 || desc->net_type == 2, "zest_mlp_train_fwd: net_type must be 0 or 2");
     Shape s;
@@ -333,6 +334,7 @@ extern "C" int zest_mlp_train_fwd(const zest_mlp_desc *desc, const float *const 
 extern "C" int zest_mlp_train_bwd(const zest_mlp_desc *desc, const float *const *params, const float *x,
                                   int M, const float *saved, const float *out, const float *g_out,
                                   float *workspace, float *g_x, float *const *g_params, void *stream) {
+    if (M == 0) return 0;                       // an empty batch is a no-op (its tensors have no storage)
     ZEST_CHECK_ARG(desc && params && x && saved && out && g_out && workspace && g_params && M > 0,
                    "zest_mlp_train_bwd: bad argument");
     Shape s;

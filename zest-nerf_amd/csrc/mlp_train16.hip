@@ -599,6 +599,7 @@ extern "C" int zest_mlp_train16_pack(const zest_mlp_desc *desc, const float *con
 
 extern "C" int zest_mlp_train16_fwd(const zest_mlp_desc *desc, const void *packed_fwd, const float *x, int M, void *stash,
                                     float *out, void *stream) {
+    if (M == 0) return 0;                       // an empty batch is a no-op (its tensors have no storage)
     ZEST_CHECK_ARG(desc && packed_fwd && x && stash && out && M > 0, "zest_mlp_train16_fwd: bad argument");
     ZEST_CHECK_ARG(((uintptr_t)stash & 15) == 0, "zest_mlp_train16_fwd: stash must be 16-byte aligned");
     TrainTables *t = tables_for(*desc);
@@ -611,6 +612,7 @@ extern "C" int zest_mlp_train16_fwd(const zest_mlp_desc *desc, const void *packe
 extern "C" int zest_mlp_train16_bwd(const zest_mlp_desc *desc, const void *packed_bwd, const float *const *params,
                                     const float *x, int M, const void *stash, const float *out, const float *g_out,
                                     void *work, float *g_x, float *const *g_params, int stages, void *stream) {
+    if (M == 0) return 0;                       // an empty batch is a no-op (its tensors have no storage)
     ZEST_CHECK_ARG(desc && packed_bwd && params && x && stash && out && g_out && work && g_x && g_params && M > 0,
                    "zest_mlp_train16_bwd: bad argument");
     ZEST_CHECK_ARG((((uintptr_t)work | (uintptr_t)stash | (uintptr_t)packed_bwd) & 15) == 0, "zest_mlp_train16_bwd: 16-byte alignment");

@@ -140,6 +140,7 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(const float *__restrict
 
 extern "C" int zest_sample_pdf_fwd(const float *bins, const float *weights, const float *u, int R, int n_bins,
                                    int n_samples, float *samples, void *stream) {
+    if (R == 0) return 0;                       // an empty batch is a no-op (its tensors have no storage)
     ZEST_CHECK_ARG(bins && weights && samples, "zest_sample_pdf_fwd: null argument");
     ZEST_CHECK_ARG(R >= 0 && n_bins >= 1 && n_bins <= kMaxBins && n_samples >= 1,
                    "zest_sample_pdf_fwd: bad shape R=%d bins=%d samples=%d (at most %d bins)", R, n_bins, n_samples, kMaxBins);
@@ -154,6 +155,7 @@ extern "C" int zest_build_rays_fwd(const float *xs, const float *ys, const float
                                    const float *k_ref, const float *near_far_tgt,
                                    const float *near_far_ref, int pad, int W, int H, float *rays_dir,
                                    float *depth, float *pts, float *ndc, void *stream) {
+    if (R == 0) return 0;                       // an empty batch is a no-op (its tensors have no storage)
     ZEST_CHECK_ARG(xs && ys && k_tgt && c2w_tgt && w2c_ref && k_ref && near_far_tgt && near_far_ref &&
                        rays_dir && depth && pts && ndc, "zest_build_rays_fwd: null argument");
     ZEST_CHECK_ARG(R >= 0 && S >= 1 && W >= 2 && H >= 2 && pad >= 0, "zest_build_rays_fwd: bad shape");
@@ -167,6 +169,7 @@ extern "C" int zest_build_rays_fwd(const float *xs, const float *ys, const float
 extern "C" int zest_ndc_fwd(const float *pts, int M, const float *w2c, const float *k, float inv_w,
                             float inv_h, float near, float far, int pad, int lindisp, float *out,
                             void *stream) {
+    if (M == 0) return 0;                       // an empty batch is a no-op (its tensors have no storage)
     ZEST_CHECK_ARG(pts && k && out, "zest_ndc_fwd: null argument");
     ZEST_CHECK_ARG(M >= 0 && pad >= 0, "zest_ndc_fwd: bad shape");
     if (M == 0) return 0;

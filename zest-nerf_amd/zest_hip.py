@@ -160,12 +160,17 @@ def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
-def _dev(t, name):
-    """Normalise to a contiguous fp32 device tensor; reject CPU tensors loudly."""
+def _dev(t, name, shape=None):
+    """Normalise to a contiguous fp32 device tensor; reject CPU tensors loudly.  shape: the extents the
+    kernel will index with (None entries: any) - the C ABI sees pointers and sizes only, so a tensor of
+    another shape would be read out of bounds: refuse it here, with both shapes in the message."""
     if t is None:
         return None
     if not t.is_cuda:
         raise RuntimeError("zest_hip: %s is on %s; this path runs only on a HIP device" % (name, t.device))
+    if shape is not None and (t.dim() != len(shape) or any(w is not None and int(w) != g for w, g in zip(shape, t.shape))):
+        raise RuntimeError("zest_hip: %s has shape %s, expected %s" % (
+            name, tuple(t.shape), tuple("*" if w is None else int(w) for w in shape)))
     if t.dtype != torch.float32:
         t = t.float()
     return t.contiguous()
@@ -175,19 +180,20 @@ def _dev(t, name):
 def _spacing(z, rays_dir, dists):
     """The sample spacing is either rebuilt in the kernel from z and |rays_dir| (depth2dist) or taken
     from the caller's `dists` [R,S]."""
-    rays_dir, dists = _dev(rays_dir, "rays_dir"), _dev(dists, "dists")
+    if z.dim() != 2:
+        raise RuntimeError("zest_hip: z has shape %s, expected (R, S)" % (tuple(z.shape),))
+    rays_dir, dists = _dev(rays_dir, "rays_dir", (z.shape[0], 3)), _dev(dists, "dists", z.shape)
     if rays_dir is None and dists is None:
         raise RuntimeError("zest_hip: compositing needs rays_dir or dists")
-    if dists is not None and tuple(dists.shape) != tuple(z.shape):
-        raise RuntimeError("zest_hip: dists %s does not match z %s" % (tuple(dists.shape), tuple(z.shape)))
     return rays_dir, dists
 
 
 def composite(raw, z, rays_dir, noise=None, noise_std=0.0, white_bkgd=False, want_disp=True, dists=None):
     """raw [R,S,4], z [R,S], rays_dir [R,3] (or dists [R,S]) -> rgb_map, disp, acc, weights, depth, alpha."""
-    raw, z, noise = _dev(raw, "raw"), _dev(z, "z"), _dev(noise, "noise")
+    z = _dev(z, "z")
     rays_dir, dists = _spacing(z, rays_dir, dists)
     R, S = z.shape
+    raw, noise = _dev(raw, "raw", (R, S, 4)), _dev(noise, "noise", (R, S))
     o = lambda *s: torch.empty(*s, device=z.device, dtype=torch.float32)
     rgb, depth, acc, disp, w, a = o(R, 3), o(R), o(R), o(R), o(R, S), o(R, S)
     _check(lib().zest_composite_fwd(_ptr(raw), _ptr(z), _ptr(rays_dir), _ptr(dists), _ptr(noise), float(noise_std),
@@ -197,10 +203,11 @@ def composite(raw, z, rays_dir, noise=None, noise_std=0.0, white_bkgd=False, wan
 
 
 def composite_blend(raw_dy, raw_st, blend, z, rays_dir, noise=None, noise_std=0.0, dists=None):
-    raw_dy, raw_st, blend = _dev(raw_dy, "raw_dy"), _dev(raw_st, "raw_st"), _dev(blend, "blend")
-    z, noise = _dev(z, "z"), _dev(noise, "noise")
+    z = _dev(z, "z")
     rays_dir, dists = _spacing(z, rays_dir, dists)
     R, S = z.shape
+    raw_dy, raw_st = _dev(raw_dy, "raw_dy", (R, S, 4)), _dev(raw_st, "raw_st", (R, S, 4))
+    blend, noise = _dev(blend, "blend", (R, S)), _dev(noise, "noise", (R, S))
     o = lambda *s: torch.empty(*s, device=z.device, dtype=torch.float32)
     rgb, depth, rgb_fg, depth_fg, w_fg, w_dy, dd = o(R, 3), o(R), o(R, 3), o(R), o(R, S), o(R, S), o(R)
     _check(lib().zest_composite_blend_fwd(_ptr(raw_dy), _ptr(raw_st), _ptr(blend), _ptr(z),
@@ -212,8 +219,9 @@ def composite_blend(raw_dy, raw_st, blend, z, rays_dir, noise=None, noise_std=0.
 
 
 def weighted_complement_sum(w, p):
-    w, p = _dev(w, "w"), _dev(p, "p")
+    w = _dev(w, "w", (None, None))
     R, S = w.shape
+    p = _dev(p, "p", (R, S))
     out = torch.empty(R, device=w.device, dtype=torch.float32)
     _check(lib().zest_weighted_complement_sum(_ptr(w), _ptr(p), R, S, _ptr(out), _stream(w)),
            "zest_weighted_complement_sum")
@@ -247,8 +255,11 @@ def volume_to_cl(vol):
 
 def distortion(weights, t_vals, want_grad=True):
     """weights [R,S], t_vals [1,S] or [R,S] -> (loss_ray [R], d loss_ray / d weights [R,S] or None)."""
-    weights, t_vals = _dev(weights, "ray_weights"), _dev(t_vals, "t_vals")
+    weights = _dev(weights, "ray_weights", (None, None))
     R, S = weights.shape
+    t_vals = _dev(t_vals, "t_vals", (None, S))
+    if t_vals.shape[0] not in (1, R):
+        raise RuntimeError("zest_hip: t_vals has %d rows, expected 1 or %d" % (t_vals.shape[0], R))
     loss = torch.empty(R, device=weights.device, dtype=torch.float32)
     grad = torch.empty(R, S, device=weights.device, dtype=torch.float32) if want_grad else None
     _check(lib().zest_distortion_fwd(_ptr(weights), _ptr(t_vals), t_vals.shape[0], R, S, _ptr(loss), _ptr(grad),
@@ -258,8 +269,11 @@ def distortion(weights, t_vals, want_grad=True):
 
 def project_rays(weights, pts, w2c, H, W, focal):
     """weights [R,S], pts [R,S,3], w2c [4,4] (or [3,4]) -> [R,2]."""
-    weights, pts, w2c = _dev(weights, "weights_ref"), _dev(pts, "raw_pts"), _dev(w2c, "w2c")
+    weights = _dev(weights, "weights_ref", (None, None))
     R, S = weights.shape
+    pts, w2c = _dev(pts, "raw_pts", (R, S, 3)), _dev(w2c, "w2c", (None, 4))
+    if w2c.shape[0] < 3:
+        raise RuntimeError("zest_hip: w2c has shape %s, expected (3 or 4, 4)" % (tuple(w2c.shape),))
     out = torch.empty(R, 2, device=weights.device, dtype=torch.float32)
     _check(lib().zest_project_rays_fwd(_ptr(weights), _ptr(pts), _ptr(w2c), int(H), int(W), float(focal), R, S,
                                        _ptr(out), _stream(weights)), "zest_project_rays_fwd")
@@ -267,9 +281,11 @@ def project_rays(weights, pts, w2c, H, W, focal):
 
 
 def project_rays_bwd(weights, pts, w2c, H, W, focal, grad_out, want_w=True, want_pts=True):
-    weights, pts, w2c, grad_out = (_dev(weights, "weights_ref"), _dev(pts, "raw_pts"), _dev(w2c, "w2c"),
-                                   _dev(grad_out, "grad"))
+    weights = _dev(weights, "weights_ref", (None, None))
     R, S = weights.shape
+    pts, w2c, grad_out = _dev(pts, "raw_pts", (R, S, 3)), _dev(w2c, "w2c", (None, 4)), _dev(grad_out, "grad", (R, 2))
+    if w2c.shape[0] < 3:
+        raise RuntimeError("zest_hip: w2c has shape %s, expected (3 or 4, 4)" % (tuple(w2c.shape),))
     dw = torch.empty(R, S, device=weights.device, dtype=torch.float32) if want_w else None
     dp = torch.empty(R, S, 3, device=weights.device, dtype=torch.float32) if want_pts else None
     _check(lib().zest_project_rays_bwd(_ptr(weights), _ptr(pts), _ptr(w2c), int(H), int(W), float(focal),
@@ -371,7 +387,8 @@ def images_to_cl(imgs):
 
 
 def volume_lookup(vol_cl, ndc):
-    ndc = _dev(ndc, "ndc")
+    ndc = _dev(ndc, "ndc", (None,) * (ndc.dim() - 1) + (3,))
+    vol_cl = _dev(vol_cl, "vol_cl", (None, None, None, 8))
     D, H, W, _ = vol_cl.shape
     M = ndc.numel() // 3
     out = torch.empty(*ndc.shape[:-1], 8, device=ndc.device, dtype=torch.float32)
@@ -381,9 +398,12 @@ def volume_lookup(vol_cl, ndc):
 
 
 def color_lookup(imgs_cl, w2cs, intrinsics, pts):
-    pts, w2cs, intrinsics = _dev(pts, "pts"), _dev(w2cs, "w2cs"), _dev(intrinsics, "intrinsics")
+    pts = _dev(pts, "pts", (None,) * (pts.dim() - 1) + (3,))
+    imgs_cl = _dev(imgs_cl, "imgs_cl", (None, None, None, 4))
+    w2cs = _dev(w2cs, "w2cs", (None,) * (w2cs.dim() - 2) + (4, 4))
+    intrinsics = _dev(intrinsics, "intrinsics", (None,) * (intrinsics.dim() - 2) + (3, 3))
     V, H, W, _ = imgs_cl.shape
-    if w2cs.shape[-3] < V or intrinsics.shape[-3] < V:
+    if w2cs.numel() < 16 * V or intrinsics.numel() < 9 * V:
         raise RuntimeError("zest_hip: %d views but only %d poses" % (V, w2cs.shape[-3]))
     M = pts.numel() // 3
     out = torch.empty(*pts.shape[:-1], 4 * V, device=pts.device, dtype=torch.float32)
@@ -394,16 +414,20 @@ def color_lookup(imgs_cl, w2cs, intrinsics, pts):
 
 def encode(ndc, pts, rays_dir, t=None, vol_cl=None, imgs_cl=None, w2cs=None, intrinsics=None):
     """ndc, pts [R,S,3]; rays_dir [R,3] -> x [R,S,C_in] (reference prepare_pts layout)."""
-    ndc, pts, rays_dir = _dev(ndc, "ndc"), _dev(pts, "pts"), _dev(rays_dir, "rays_dir")
-    w2cs, intrinsics = _dev(w2cs, "w2cs"), _dev(intrinsics, "intrinsics")
+    ndc = _dev(ndc, "ndc", (None, None, 3))
     R, S, _ = ndc.shape
+    pts, rays_dir = _dev(pts, "pts", (R, S, 3)), _dev(rays_dir, "rays_dir", (R, 3))
+    w2cs, intrinsics = _dev(w2cs, "w2cs"), _dev(intrinsics, "intrinsics")
     has_t = t is not None
     D = Hv = Wv = V = H = W = 0
     if vol_cl is not None:
+        vol_cl, imgs_cl = _dev(vol_cl, "vol_cl", (None, None, None, 8)), _dev(imgs_cl, "imgs_cl", (None, None, None, 4))
         D, Hv, Wv, _ = vol_cl.shape
         V, H, W, _ = imgs_cl.shape
-        if w2cs is None or w2cs.shape[-3] < V:
-            raise RuntimeError("zest_hip: encode needs one pose per source view")
+        if pts is None or w2cs is None or intrinsics is None or w2cs.numel() < 16 * V or intrinsics.numel() < 9 * V:
+            raise RuntimeError("zest_hip: encode with features needs pts and one pose (4x4) and intrinsic (3x3) per source view")
+    if w2cs is not None and w2cs.shape[-2:] != (4, 4):
+        raise RuntimeError("zest_hip: w2cs has shape %s, expected (..., 4, 4)" % (tuple(w2cs.shape),))
     c_in = (4 if has_t else 3) * 21 + (8 + 4 * V if vol_cl is not None else 0) + 27
     x = torch.empty(R, S, c_in, device=ndc.device, dtype=torch.float32)
     _check(lib().zest_encode_fwd(_ptr(ndc), _ptr(pts), _ptr(rays_dir), R, S, int(has_t),
@@ -417,9 +441,13 @@ def encode(ndc, pts, rays_dir, t=None, vol_cl=None, imgs_cl=None, w2cs=None, int
 def build_rays(xs, ys, t_rand, S, k_tgt, c2w_tgt, w2c_ref, k_ref, nf_tgt, nf_ref, pad, W, H):
     """xs, ys [R] pixel coordinates; camera matrices and (near, far) pairs as device tensors
     (views into the batch dict) -> rays_dir [R,3], depth [R,S], pts, ndc [R,S,3]."""
-    xs, ys, t_rand = _dev(xs, "xs"), _dev(ys, "ys"), _dev(t_rand, "t_rand")
-    mats = [_dev(m, "camera") for m in (k_tgt, c2w_tgt, w2c_ref, k_ref, nf_tgt, nf_ref)]
+    xs = _dev(xs, "xs")
     R = xs.numel()
+    ys, t_rand = _dev(ys, "ys", xs.shape), _dev(t_rand, "t_rand")
+    if t_rand is not None and (t_rand.dim() != 2 or t_rand.shape[0] < R or t_rand.shape[1] != S):
+        raise RuntimeError("zest_hip: t_rand has shape %s, expected (>= %d, %d)" % (tuple(t_rand.shape), R, S))
+    mats = [_dev(m, n, sh) for m, n, sh in ((k_tgt, "k_tgt", (3, 3)), (c2w_tgt, "c2w_tgt", (4, 4)), (w2c_ref, "w2c_ref", (4, 4)),
+                                           (k_ref, "k_ref", (3, 3)), (nf_tgt, "near_far_tgt", (2,)), (nf_ref, "near_far_ref", (2,)))]
     o = lambda *s: torch.empty(*s, device=xs.device, dtype=torch.float32)
     d, z, pts, ndc = o(R, 3), o(R, S), o(R, S, 3), o(R, S, 3)
     _check(lib().zest_build_rays_fwd(_ptr(xs), _ptr(ys), _ptr(t_rand), R, int(S), *[_ptr(m) for m in mats],
@@ -430,10 +458,9 @@ def build_rays(xs, ys, t_rand, S, k_tgt, c2w_tgt, w2c_ref, k_ref, nf_tgt, nf_ref
 
 def sample_pdf(bins, weights, n_samples=None, u=None):
     """bins [R, Nb+1], weights [R, Nb], u [R, Ns] (or None + n_samples: deterministic) -> samples [R, Ns]."""
-    bins, weights, u = _dev(bins, "bins"), _dev(weights, "weights"), _dev(u, "u")
+    weights = _dev(weights, "weights", (None, None))
     R, Nb = weights.shape
-    if tuple(bins.shape) != (R, Nb + 1):
-        raise RuntimeError("zest_hip.sample_pdf: bins %s for weights %s" % (tuple(bins.shape), tuple(weights.shape)))
+    bins, u = _dev(bins, "bins", (R, Nb + 1)), _dev(u, "u", (R, None))
     Ns = u.shape[1] if u is not None else int(n_samples)
     out = torch.empty(R, Ns, device=bins.device, dtype=torch.float32)
     _check(lib().zest_sample_pdf_fwd(_ptr(bins), _ptr(weights), _ptr(u), R, Nb, Ns, _ptr(out), _stream(bins)),
@@ -442,7 +469,8 @@ def sample_pdf(bins, weights, n_samples=None, u=None):
 
 
 def ndc_coordinate(pts, w2c, k, inv_w, inv_h, near, far, pad=0, lindisp=False):
-    pts, w2c, k = _dev(pts, "pts"), _dev(w2c, "w2c"), _dev(k, "k")
+    pts = _dev(pts, "pts", (None,) * (pts.dim() - 1) + (3,))
+    w2c, k = _dev(w2c, "w2c", (4, 4)), _dev(k, "k", (3, 3))
     M = pts.numel() // 3
     out = torch.empty_like(pts)
     _check(lib().zest_ndc_fwd(_ptr(pts), M, _ptr(w2c), _ptr(k), float(inv_w), float(inv_h), float(near),
@@ -452,10 +480,12 @@ def ndc_coordinate(pts, w2c, k, inv_w, inv_h, near, far, pad=0, lindisp=False):
 
 
 def composite_bwd(raw, z, rays_dir, noise, noise_std, white_bkgd, g_rgb, g_depth, g_acc, g_weights, dists=None):
-    raw, z, noise = _dev(raw, "raw"), _dev(z, "z"), _dev(noise, "noise")
+    z = _dev(z, "z")
     rays_dir, dists = _spacing(z, rays_dir, dists)
-    gs = [_dev(g, "grad") for g in (g_rgb, g_depth, g_acc, g_weights)]
     R, S = z.shape
+    raw, noise = _dev(raw, "raw", (R, S, 4)), _dev(noise, "noise", (R, S))
+    gs = [_dev(g, n, sh) for g, n, sh in ((g_rgb, "g_rgb", (R, 3)), (g_depth, "g_depth", (R,)), (g_acc, "g_acc", (R,)),
+                                          (g_weights, "g_weights", (R, S)))]
     g_raw = torch.empty(R, S, 4, device=z.device, dtype=torch.float32)
     _check(lib().zest_composite_bwd(_ptr(raw), _ptr(z), _ptr(rays_dir), _ptr(dists), _ptr(noise), float(noise_std),
                                     int(bool(white_bkgd)), R, S, *[_ptr(g) for g in gs], _ptr(g_raw),
@@ -465,11 +495,14 @@ def composite_bwd(raw, z, rays_dir, noise, noise_std, white_bkgd, g_rgb, g_depth
 
 def composite_blend_bwd(raw_dy, raw_st, blend, z, rays_dir, noise, noise_std, g_rgb, g_depth, g_rgb_fg,
                         g_depth_fg, g_wfg, g_wd, dists=None):
-    raw_dy, raw_st, blend = _dev(raw_dy, "raw_dy"), _dev(raw_st, "raw_st"), _dev(blend, "blend")
-    z, noise = _dev(z, "z"), _dev(noise, "noise")
+    z = _dev(z, "z")
     rays_dir, dists = _spacing(z, rays_dir, dists)
-    gs = [_dev(g, "grad") for g in (g_rgb, g_depth, g_rgb_fg, g_depth_fg, g_wfg, g_wd)]
     R, S = z.shape
+    raw_dy, raw_st = _dev(raw_dy, "raw_dy", (R, S, 4)), _dev(raw_st, "raw_st", (R, S, 4))
+    blend, noise = _dev(blend, "blend", (R, S)), _dev(noise, "noise", (R, S))
+    gs = [_dev(g, n, sh) for g, n, sh in ((g_rgb, "g_rgb", (R, 3)), (g_depth, "g_depth", (R,)), (g_rgb_fg, "g_rgb_fg", (R, 3)),
+                                          (g_depth_fg, "g_depth_fg", (R,)), (g_wfg, "g_weights_fg", (R, S)),
+                                          (g_wd, "g_weights_dy", (R, S)))]
     o = lambda *s: torch.empty(*s, device=z.device, dtype=torch.float32)
     g_dy, g_st, g_b = o(R, S, 4), o(R, S, 4), o(R, S)
     _check(lib().zest_composite_blend_bwd(_ptr(raw_dy), _ptr(raw_st), _ptr(blend), _ptr(z), _ptr(rays_dir),
@@ -482,11 +515,14 @@ def composite_blend_bwd(raw_dy, raw_st, blend, z, rays_dir, noise, noise_std, g_
 # ------------------------------------------------------------------- training path (backward)
 def encode_bwd(g_x, ndc, t, vol_cl, V, want_vol_grad):
     """-> g_ndc [R,S,3], g_vol_cl [D,H,W,8] or None."""
-    g_x, ndc = _dev(g_x, "g_x"), _dev(ndc, "ndc")
+    ndc = _dev(ndc, "ndc", (None, None, 3))
     R, S, _ = ndc.shape
+    c_in = (4 if t is not None else 3) * 21 + (8 + 4 * int(V) if vol_cl is not None else 0) + 27
+    g_x = _dev(g_x, "g_x", (R, S, c_in))
     D = Hv = Wv = 0
     g_vol = None
     if vol_cl is not None:
+        vol_cl = _dev(vol_cl, "vol_cl", (None, None, None, 8))
         D, Hv, Wv, _ = vol_cl.shape
         if want_vol_grad:
             g_vol = torch.zeros_like(vol_cl)
@@ -498,6 +534,7 @@ def encode_bwd(g_x, ndc, t, vol_cl, V, want_vol_grad):
 
 
 def volume_from_cl(vol_cl):
+    vol_cl = _dev(vol_cl, "vol_cl", (None, None, None, 8))
     D, H, W, _ = vol_cl.shape
     out = torch.empty(1, 8, D, H, W, device=vol_cl.device, dtype=torch.float32)
     _check(lib().zest_volume_from_cl(_ptr(vol_cl), D, H, W, _ptr(out), _stream(vol_cl)), "zest_volume_from_cl")
@@ -508,15 +545,59 @@ def _ptr_table(tensors):
     return (_vp * (2 * P_COUNT))(*[_ptr(t) for t in tensors])
 
 
+def param_shapes(desc):
+    """{ZEST_P_* slot: weight shape} of the Linears a net of this descriptor has (bias: (rows,))."""
+    W, P, skips = desc.W, desc.in_ch_pts, desc.skips
+    sh = {l: (W, P if l == 0 else W + (P if (l - 1) in skips else 0)) for l in range(desc.D)}
+    if desc.use_feat:
+        sh[8] = (W, desc.in_ch_feat)
+    sh.update({9: (W // 2, W + desc.in_ch_views), 10: (W, W), 11: (1, W), 12: (3, W // 2)})
+    if desc.head == HEAD_BLEND:
+        sh[13] = (1, W)
+    elif desc.head == HEAD_DYNAMIC:
+        sh[13], sh[14] = (6, W), (2, W)
+    return sh
+
+
+def _params(desc, params):
+    """The 2*P_COUNT parameter table as contiguous fp32 device tensors, every present tensor checked against the
+    shape the packer / the training GEMMs will index it with (a state dict of another architecture must not be
+    read out of bounds)."""
+    if len(params) != 2 * P_COUNT:
+        raise RuntimeError("zest_hip: parameter table has %d entries, expected %d" % (len(params), 2 * P_COUNT))
+    want = param_shapes(desc)
+    keep = []
+    for i, p in enumerate(params):
+        slot, is_bias = i // 2, i % 2
+        if p is None:
+            if slot in want:
+                raise RuntimeError("zest_hip: parameter slot %d (%s) is required by this net" % (slot, "bias" if is_bias else "weight"))
+            keep.append(None)
+            continue
+        if slot not in want:
+            keep.append(None)            # a tensor the descriptor has no use for (e.g. pts_bias of a net without features)
+            continue
+        shape = (want[slot][0],) if is_bias else want[slot]
+        keep.append(_dev(p, "parameter slot %d %s" % (slot, "bias" if is_bias else "weight"), shape))
+    return keep
+
+
+def _mlp_rows(desc, x, name="x"):
+    x = _dev(x, name)
+    if x.dim() < 1 or x.shape[-1] != desc.in_ch:
+        raise RuntimeError("zest_hip: MLP expects %d input channels, got shape %s" % (desc.in_ch, tuple(x.shape)))
+    return x
+
+
 def mlp_train_fwd(desc, params, x):
     """params: 2*P_COUNT tensors-or-None.  -> out [M,C_out], saved (opaque activation stash)."""
-    x = _dev(x, "x")
+    x = _mlp_rows(desc, x)
     M = x.numel() // x.shape[-1]
     L = lib()
     saved = torch.empty(int(L.zest_mlp_train_saved_floats(C.byref(desc), M)), device=x.device)
     work = torch.empty(int(L.zest_mlp_train_workspace_floats(C.byref(desc), M)), device=x.device)
     out = torch.empty(*x.shape[:-1], desc.out_ch, device=x.device, dtype=torch.float32)
-    keep = [(_dev(p, "param") if p is not None else None) for p in params]
+    keep = _params(desc, params)
     _check(L.zest_mlp_train_fwd(C.byref(desc), _ptr_table(keep), _ptr(x), M, _ptr(saved), _ptr(work), _ptr(out),
                                 _stream(x)), "zest_mlp_train_fwd")
     return out, saved
@@ -524,11 +605,14 @@ def mlp_train_fwd(desc, params, x):
 
 def mlp_train_bwd(desc, params, x, saved, out, g_out, want_gx=True):
     """-> g_x [.., C_in] or None, list of 2*P_COUNT parameter gradients (None where absent)."""
-    x, g_out = _dev(x, "x"), _dev(g_out, "g_out")
+    x = _mlp_rows(desc, x)
     M = x.numel() // x.shape[-1]
+    g_out, out = _dev(g_out, "g_out", x.shape[:-1] + (desc.out_ch,)), _dev(out, "out", x.shape[:-1] + (desc.out_ch,))
     L = lib()
+    if saved.numel() < int(L.zest_mlp_train_saved_floats(C.byref(desc), M)):
+        raise RuntimeError("zest_hip: `saved` is not the stash of this forward call (too small)")
     work = torch.empty(int(L.zest_mlp_train_workspace_floats(C.byref(desc), M)), device=x.device)
-    keep = [(_dev(p, "param") if p is not None else None) for p in params]
+    keep = _params(desc, params)
     grads = [(torch.empty_like(p) if p is not None else None) for p in keep]
     g_x = torch.empty_like(x) if want_gx else None
     _check(L.zest_mlp_train_bwd(C.byref(desc), _ptr_table(keep), _ptr(x), M, _ptr(saved), _ptr(out), _ptr(g_out),
@@ -540,8 +624,11 @@ def mlp_train_bwd(desc, params, x, saved, out, g_out, want_gx=True):
 def mlp_train16_pack_bwd(desc, params):
     """Transposed weight stream of the backward data kernel (params as for mlp_pack)."""
     dev = next(p for p in params if p is not None).device
-    keep = [(_dev(p, "param") if p is not None else None) for p in params]
-    packed = torch.empty(int(lib().zest_mlp_train16_packed_bytes(C.byref(desc))), device=dev, dtype=torch.uint8)
+    keep = _params(desc, params)
+    nbytes = int(lib().zest_mlp_train16_packed_bytes(C.byref(desc)))
+    if nbytes == 0:
+        raise RuntimeError("zest_mlp_train16_packed_bytes: %s" % (lib().zest_last_error() or b"").decode())
+    packed = torch.empty(nbytes, device=dev, dtype=torch.uint8)
     _check(lib().zest_mlp_train16_pack(C.byref(desc), _ptr_table(keep), _ptr(packed),
                                        torch.cuda.current_stream(dev).cuda_stream), "zest_mlp_train16_pack")
     return packed
@@ -549,7 +636,7 @@ def mlp_train16_pack_bwd(desc, params):
 
 def mlp_train16_fwd(desc, packed_fwd, x):
     """x [M, C_in] -> out [M, C_out], stash (opaque: layer outputs as bf16 operand tiles + ReLU masks)."""
-    x = _dev(x, "x")
+    x = _mlp_rows(desc, x)
     M = x.numel() // x.shape[-1]
     stash = torch.empty(int(lib().zest_mlp_train16_stash_bytes(C.byref(desc), M)), device=x.device, dtype=torch.uint8)
     out = torch.empty(*x.shape[:-1], desc.out_ch, device=x.device, dtype=torch.float32)
@@ -560,12 +647,15 @@ def mlp_train16_fwd(desc, packed_fwd, x):
 
 def mlp_train16_bwd(desc, packed_bwd, params, x, stash, out, g_out, stages=7, work=None):
     """-> g_x [M, C_in] (direction columns zero), list of 2*P_COUNT fp32 parameter gradients (None where absent)."""
-    x, g_out, out = _dev(x, "x"), _dev(g_out, "g_out"), _dev(out, "out")
+    x = _mlp_rows(desc, x)
     M = x.numel() // x.shape[-1]
+    g_out, out = _dev(g_out, "g_out", x.shape[:-1] + (desc.out_ch,)), _dev(out, "out", x.shape[:-1] + (desc.out_ch,))
+    if stash.numel() < int(lib().zest_mlp_train16_stash_bytes(C.byref(desc), M)):
+        raise RuntimeError("zest_hip: `stash` is not the stash of this forward call (too small)")
     need = int(lib().zest_mlp_train16_work_bytes(C.byref(desc), M))
     if work is None or work.numel() < need:
         work = torch.empty(need, device=x.device, dtype=torch.uint8)
-    keep = [(_dev(p, "param") if p is not None else None) for p in params]
+    keep = _params(desc, params)
     # the gradients are accumulated with atomics: one zero-filled buffer (one fill launch), views into it
     sizes = [(p.numel() + 3) // 4 * 4 if p is not None else 0 for p in keep]
     flat = torch.zeros(sum(sizes), device=x.device, dtype=torch.float32)
@@ -588,11 +678,11 @@ def mlp_packed_bytes(desc, precision):
 def mlp_pack(desc, precision, params):
     """params: list of 2*P_COUNT tensors-or-None (weight, bias per ZEST_P_* slot)."""
     dev = next(p for p in params if p is not None).device
-    keep = [(_dev(p, "param") if p is not None else None) for p in params]
-    arr = (_vp * (2 * P_COUNT))(*[_ptr(p) for p in keep])
     nbytes = mlp_packed_bytes(desc, precision)
     if nbytes == 0:                      # shape / precision the kernels refuse: the library says which
         raise RuntimeError("zest_mlp_packed_bytes: %s" % (lib().zest_last_error() or b"").decode())
+    keep = _params(desc, params)
+    arr = (_vp * (2 * P_COUNT))(*[_ptr(p) for p in keep])
     packed = torch.empty(nbytes, device=dev, dtype=torch.uint8)
     _check(lib().zest_mlp_pack(C.byref(desc), int(precision), arr, _ptr(packed),
                                torch.cuda.current_stream(dev).cuda_stream), "zest_mlp_pack")
@@ -600,10 +690,10 @@ def mlp_pack(desc, precision, params):
 
 
 def mlp_fwd(desc, precision, packed, x):
-    x = _dev(x, "x")
-    if x.shape[-1] != desc.in_ch:
-        raise RuntimeError("zest_hip: MLP expects %d input channels, got %d" % (desc.in_ch, x.shape[-1]))
+    x = _mlp_rows(desc, x)
     M = x.numel() // x.shape[-1]
+    if packed is None or packed.numel() * packed.element_size() < mlp_packed_bytes(desc, precision):
+        raise RuntimeError("zest_hip: `packed` is not the packed weights of this net and precision (too small)")
     out = torch.empty(*x.shape[:-1], desc.out_ch, device=x.device, dtype=torch.float32)
     _check(lib().zest_mlp_fwd(C.byref(desc), int(precision), _ptr(packed), _ptr(x), M, _ptr(out),
                               _stream(x)), "zest_mlp_fwd")
@@ -691,10 +781,17 @@ def render_fused(ndc, pts, z, rays_dir, desc_s, packed_s, views_s, desc_d=None, 
     Returns out [R,16] (column layout: include/zest_render.h)."""
     if precision not in ENGINE_PRECISIONS:
         raise RuntimeError("zest_hip.render_fused: precision %r is not an engine operand type" % (precision,))
-    ndc, pts, z, rays_dir = _dev(ndc, "ndc"), _dev(pts, "pts"), _dev(z, "z"), _dev(rays_dir, "rays_dir")
+    z = _dev(z, "z", (None, None))
     R, S = z.shape
+    ndc, pts, rays_dir = _dev(ndc, "ndc", (R, S, 3)), _dev(pts, "pts", (R, S, 3)), _dev(rays_dir, "rays_dir", (R, 3))
+    for d_, pk, what in ((desc_s, packed_s, "static"), (desc_d, packed_d, "dynamic")):
+        if d_ is not None and (pk is None or pk.numel() * pk.element_size() < mlp_packed_bytes(d_, precision)):
+            raise RuntimeError("zest_hip.render_fused: the %s net's packed weights do not belong to its descriptor "
+                               "and this precision (too small)" % what)
     if out is None:
         out = torch.empty(R, 16, device=z.device, dtype=torch.float32)
+    elif tuple(out.shape) != (R, 16) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise RuntimeError("zest_hip.render_fused: out must be a contiguous fp32 [%d, 16] tensor" % R)
     need = int(lib().zest_render_fused_workspace(R, S))
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(need, device=z.device, dtype=torch.uint8)

@@ -71,6 +71,20 @@ def test_configs3_ray_ranges_equal_the_dense_shape_bit_for_bit(hip, rays):
     assert torch.equal(outs["dense"], outs["ranges"]) and torch.equal(outs["dense"], outs[None])
 
 
+def test_large_batch_equals_its_shards(hip):
+    """50 000 rays x 128 samples in one call (6.4 M samples, 196 rays per workgroup: ~98 passes each) give, bit for
+    bit, the rows of the same rays rendered in three uneven shards - index arithmetic at the large end, ray ranges
+    that do not divide evenly, and the multi-GPU sharding argument at whole-image scale."""
+    d = _workload("nsff_static_mvs_1024x128", rays=50000)
+    keys = ("rays_pts", "rays_ndc", "depth_candidates", "rays_dir")
+    full = _maps(d)["zest_packed_maps"].clone()
+    assert full.shape == (50000, 16) and torch.isfinite(full).all()
+    orig = {k: d.t[k] for k in keys}
+    for lo, hi in ((0, 1), (1, 20001), (20001, 50000)):
+        d.t = {k: orig[k][:, lo:hi].contiguous() for k in keys}
+        assert torch.equal(_maps(d)["zest_packed_maps"], full[lo:hi]), (lo, hi)
+
+
 def test_fused_ray_permutation_and_sharding_invariance(hip):
     """Rays are independent units: permuting the batch permutes the maps bit for bit, and rendering
     two halves separately gives the rows of the full render (the multi-GPU sharding argument)."""

@@ -55,5 +55,36 @@ __device__ __forceinline__ void load_feat_operand(const float *__restrict__ xf, 
     }
 }
 
+// One k-tile of the same operands with the k-tile index at run time, as the eight fp32 values of the lane (the
+// weight kernel of the training path gives each k-tile to a wave of its own and requests the values one block of
+// samples ahead: they are rounded and packed only when they are stored): same columns as above, the divisions by
+// C are a few VALU instructions against the latency of the row loads.
+template <int C, int L>
+__device__ __forceinline__ void load_pe_tile_raw(const float *__restrict__ xrow, bool valid, int grp, int t, float (&v)[8]) {
+    const float *xg = xrow + (grp >> 1) * 2 * C + (grp & 1) * C;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int m = 8 * t + e;
+        const bool in_bands = m < (L / 2) * C;
+        const int col = in_bands ? C + 4 * C * (m / C) + m % C : 0;
+        const float band = (valid && in_bands) ? xg[col] : 0.0f;
+        const float raw = (valid && m == (L / 2) * C && grp < C) ? xrow[grp < C ? grp : 0] : 0.0f;
+        v[e] = in_bands ? band : raw;
+    }
+}
+
+__device__ __forceinline__ void load_feat_tile_raw(const float *__restrict__ xf, int F, bool valid, int grp, int t, float (&v)[8]) {
+    int ca, cb;
+    if (t == 0) {
+        ca = grp == 0 ? 0 : (grp == 1 ? 4 : 8 * grp);
+        cb = grp == 0 ? 8 : (grp == 1 ? 12 : 8 * grp + 4);
+    } else {
+        ca = 32 * t + 8 * grp, cb = ca + 4;
+    }
+    const bool va = valid && ca + 4 <= F, vb = valid && cb + 4 <= F;
+    const float *pa = xf + (va ? ca : 0), *pb = xf + (vb ? cb : 0);
+#pragma unroll
+    for (int c = 0; c < 4; c++) v[c] = va ? pa[c] : 0.0f, v[4 + c] = vb ? pb[c] : 0.0f;
+}
 
 }  // namespace zest

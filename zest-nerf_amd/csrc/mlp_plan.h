@@ -148,6 +148,7 @@ struct DwJob {
     int32_t in_kind;                     // 0: activation-stash tiles, 1: point operand (from x), 2: feature operand, 3: direction operand
     int32_t in_tile0, n_in_tiles;
     int32_t ld, col0, want_bias;
+    int32_t wg0, n_wg;                   // workgroups of the weight kernel that share this job (set per device at upload)
     int16_t out_slot[256], out_row[256]; // output position -> (ZEST_P_* slot, row of its weight), -1: none
     int16_t in_col[256];                 // input position -> column (before col0), -1: none
 };

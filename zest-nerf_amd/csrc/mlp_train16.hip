@@ -396,17 +396,22 @@ __device__ __forceinline__ bf16x8 tr_operand(unsigned img_addr, int p0, int lane
 }
 
 __global__ __launch_bounds__(kWaves * 64, kWaves / 4) void train16_dw_kernel(
-    const DwJob *__restrict__ jobs, int wg_per_job, const uint4 *__restrict__ stash, const uint4 *__restrict__ grad,
+    const DwJob *__restrict__ jobs, int n_jobs, const uint4 *__restrict__ stash, const uint4 *__restrict__ grad,
     const float *__restrict__ x, int M, int P, int F, int C_in, int pts_c, float *const *__restrict__ g_params) {
     constexpr int CB = 2;
     __shared__ __attribute__((aligned(16))) char img[2][2][kImgBytes];      // [buffer][0: out (gradient), 1: in][...]
-    const DwJob &job = jobs[blockIdx.x / wg_per_job];
-    const int part = blockIdx.x % wg_per_job;
+    // jobs own runs of workgroups in proportion to the tiles they stream per block (tables_for)
+    int ji = 0;
+    for (int j = 1; j < n_jobs; j++)
+        if ((int)blockIdx.x >= jobs[j].wg0) ji = j;
+    const DwJob &job = jobs[ji];
+    const int part = (int)blockIdx.x - job.wg0, wg_per_job = job.n_wg;
     const int lane = threadIdx.x & 63, col = lane & 15, grp = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long n_blocks = ((long long)M + 31) / 32;
     const long long per = (n_blocks + wg_per_job - 1) / wg_per_job;
     const long long b0 = part * per, b1 = min(n_blocks, b0 + per);
+    if (b0 >= b1) return;                  // fewer blocks than workgroups (tiny batches): nothing to add
     const int n_in = job.n_in_tiles, n_out = job.n_out_tiles;
     f32x4 acc[2][16], accb[2];
 #pragma unroll
@@ -421,12 +426,39 @@ __global__ __launch_bounds__(kWaves * 64, kWaves / 4) void train16_dw_kernel(
     // block b + 1 are requested before block b is computed, so their HBM latency hides behind the MFMAs
     const int items = (n_out + (job.in_kind == 0 ? n_in : 0)) * CB;
     auto fetch_item = [&](long long b, int it) {
+#ifdef ZEST_DW_EXP_NO_LOADS            // timing experiment only: every block reads the first one again (L2 hits)
+        b = b0;
+#endif
         const int t = it / CB, cb = it % CB;
         const bool is_out = t < n_out;
         const int kt = is_out ? t : t - n_out;
         return is_out ? grad[(((size_t)b * kGradTiles + job.out_tile0 + kt) * CB + cb) * 64 + lane]
                       : stash[(((size_t)b * kStashTiles + job.in_tile0 + kt) * CB + cb) * 64 + lane];
     };
+    // Operands that are not in the stash (the encoder's: points, features, directions) are rebuilt from the rows of
+    // x: wave w takes column block w % CB, k-tile w / CB (at most 3 k-tiles: six waves side by side), and requests
+    // its eight values one block ahead of their use, like the tiles.
+#ifndef ZEST_DW_EXP_NO_REBUILD         // (defined: timing experiment only)
+    const bool rebuild = job.in_kind != 0 && wave < CB * n_in;
+#else
+    const bool rebuild = false;
+#endif
+    const int rb_cb = wave % CB, rb_kt = wave / CB;
+    float xraw[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto fetch_raw = [&](long long b) {
+        const long long m = b * 32 + 16 * rb_cb + col;
+        const bool valid = m < M;
+        const float *xr = x + (size_t)(valid ? m : 0) * C_in;
+        if (job.in_kind == 1) {
+            if (pts_c == 3) load_pe_tile_raw<3, 10>(xr, valid, grp, rb_kt, xraw);
+            else load_pe_tile_raw<4, 10>(xr, valid, grp, rb_kt, xraw);
+        } else if (job.in_kind == 2) {
+            load_feat_tile_raw(xr + P, F, valid, grp, rb_kt, xraw);
+        } else {
+            load_pe_tile_raw<3, 4>(xr + P + F, valid, grp, rb_kt, xraw);
+        }
+    };
+    if (rebuild) fetch_raw(b0);
     // tiles of blocks b .. b + kDwAhead - 1: requested kDwAhead blocks ahead of their use (HBM latency under the
     // load of 255 workgroups streaming is several microseconds; a block is ~2 us of work)
 #ifndef ZEST_DW_AHEAD
@@ -452,33 +484,11 @@ __global__ __launch_bounds__(kWaves * 64, kWaves / 4) void train16_dw_kernel(
             const int kt = is_out ? t : t - n_out;
             *reinterpret_cast<uint4 *>((is_out ? im_out : im_in) + (16 * cb + col) * kImgStride + kt * 64 + grp * 16) = pre[0][i];
         }
-        if (job.in_kind != 0 && wave < CB) {            // operands rebuilt from the rows of x: one column block per wave
-            const int cb = wave;
-            const long long m = b * 32 + 16 * cb + col;
-            const bool valid = m < M;
-            const float *xr = x + (size_t)(valid ? m : 0) * C_in;
-            OpArr<3> o3;
-            if (job.in_kind == 1) {
-                if (pts_c == 3) {
-                    OpArr<2> o2;
-                    load_pe_operand<EP, 3, 10, 2>(xr, valid, grp, o2);
-                    o3.t[0][0] = o2.t[0][0], o3.t[0][1] = o2.t[0][1];
-                } else {
-                    load_pe_operand<EP, 4, 10, 3>(xr, valid, grp, o3);
-                }
-            } else if (job.in_kind == 2) {
-                OpArr<2> o2;
-                load_feat_operand<EP, 2>(xr + P, F, valid, grp, o2);
-                o3.t[0][0] = o2.t[0][0], o3.t[0][1] = o2.t[0][1];
-            } else {
-                OpArr<1> o1;
-                load_pe_operand<EP, 3, 4, 1>(xr + P + F, valid, grp, o1);
-                o3.t[0][0] = o1.t[0][0];
-            }
-            for (int kt = 0; kt < n_in; kt++) {
-                const bf16x8 tq = kt == 0 ? o3.t[0][0] : (kt == 1 ? o3.t[0][1] : o3.t[0][2]);
-                *reinterpret_cast<uint4 *>(im_in + (16 * cb + col) * kImgStride + kt * 64 + grp * 16) = __builtin_bit_cast(uint4, tq);
-            }
+        // operands that are not in the stash were requested from the rows of x one block ahead (xraw): round, pack, store
+        if (rebuild) {
+            OpArr<1, 1> o;
+            store_tile<EP>(xraw, o, 0);
+            *reinterpret_cast<uint4 *>(im_in + (16 * rb_cb + col) * kImgStride + rb_kt * 64 + grp * 16) = __builtin_bit_cast(uint4, o.t[0][0]);
         }
         __syncthreads();
 #pragma unroll
@@ -487,7 +497,12 @@ __global__ __launch_bounds__(kWaves * 64, kWaves / 4) void train16_dw_kernel(
             for (int d = 0; d + 1 < kDwAhead; d++) pre[d][i] = pre[d + 1][i];
             if (b + kDwAhead < b1 && wave + 8 * i < items) pre[kDwAhead - 1][i] = fetch_item(b + kDwAhead, wave + 8 * i);
         }
+        if (rebuild && b + 1 < b1) fetch_raw(b + 1);
+#ifdef ZEST_DW_EXP_NO_MFMA             // timing experiment only
+        if (b == b0 && wave < n_out) {
+#else
         if (wave < n_out) {
+#endif
             const unsigned a_out = img0 + (unsigned)(buf * 2) * kImgBytes, a_in = a_out + kImgBytes;
             bf16x8 A[2];
 #pragma unroll
@@ -506,6 +521,9 @@ __global__ __launch_bounds__(kWaves * 64, kWaves / 4) void train16_dw_kernel(
             }
         }
     }
+#ifdef ZEST_DW_EXP_NO_ATOMICS          // timing experiment only: results are wrong
+    if (acc[0][0][0] != 123456.0f) return;
+#endif
     if (wave >= n_out) return;
     // ---- add this workgroup's slice to the fp32 gradients: accumulator (rt, ct): rows = output positions
     // 32 wave + 16 rt + 4 g + r, column = input position 16 ct + col
@@ -530,7 +548,7 @@ __global__ __launch_bounds__(kWaves * 64, kWaves / 4) void train16_dw_kernel(
 // ------------------------------------------------------------------------------ host side
 struct TrainTables {                 // per MLP shape, device resident
     DwJob *jobs = nullptr;
-    int n_jobs = 0;
+    int n_jobs = 0, n_wg = 0;        // weight kernel: jobs and the workgroups they share (one per CU)
     short *map_pts = nullptr, *map_feat = nullptr;
     MlpPlan fwd;                     // forward plan (stream size check, operand tile counts)
 };
@@ -552,6 +570,36 @@ TrainTables *tables_for(const zest_mlp_desc &d) {
         return nullptr;
     }
     t->n_jobs = (int)jobs.size();
+    {   // Workgroups per job.  The time of a job is set by its number of blocks per workgroup: an iteration costs
+        // about the same 2 us whether it stages 5 tiles or 16 (latency of the stage -> rendezvous -> transposing
+        // reads -> MFMA chain, not bandwidth), so a split in proportion to the tiles a job streams leaves the light
+        // jobs (rgb: 5 tiles, 7 workgroups) running 1.6x longer than an even one (measured: 990 us against 600).
+        // The jobs that rebuild an operand from the rows of x pay ~20 % more per iteration (4-byte gathers: one
+        // cache-line request per lane and element) and get that many more workgroups.
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            cus = 256;
+        const int nj = t->n_jobs;
+        if (cus < nj) cus = nj;
+        std::vector<int> cost(nj), wgs(nj);
+        int total = 0, given = 0;
+        for (int j = 0; j < nj; j++) total += cost[j] = jobs[j].in_kind != 0 ? 12 : 10;
+        for (int j = 0; j < nj; j++) given += wgs[j] = std::max(1, (int)((long long)cus * cost[j] / total));
+        while (given != cus) {          // rounding remainder: to the job with the most cost per workgroup / from the one with the least
+            int pick = -1;
+            for (int j = 0; j < nj; j++) {
+                if (given > cus && wgs[j] <= 1) continue;
+                if (pick < 0) { pick = j; continue; }
+                const long long a = (long long)cost[j] * wgs[pick], b = (long long)cost[pick] * wgs[j];
+                if (given < cus ? a > b : a < b) pick = j;
+            }
+            if (given < cus) wgs[pick]++, given++;
+            else wgs[pick]--, given--;
+        }
+        for (int j = 0, w0 = 0; j < nj; j++) jobs[j].wg0 = w0, jobs[j].n_wg = wgs[j], w0 += wgs[j];
+        t->n_wg = cus;
+    }
     std::vector<short> mp(96, -1), mf(64, -1);
     for (size_t i = 0; i < t->fwd.map_pts.size() && i < 96; i++) mp[i] = t->fwd.map_pts[i];
     for (size_t i = 0; i < t->fwd.map_feat.size() && i < 64; i++) mf[i] = t->fwd.map_feat[i];
@@ -680,13 +728,9 @@ extern "C" int zest_mlp_train16_bwd(const zest_mlp_desc *desc, const void *packe
             zest_set_error("zest_mlp_train16_bwd: uploading the gradient pointers: %s", hipGetErrorString(e));
             return (int)e;
         }
-        // one resident workgroup per CU (128 accumulator registers per lane): more workgroups per job would only
-        // run in a second round and add their 256 KB of gradient atomics each
-        int wg_per_job = cus / t->n_jobs;
-        if (wg_per_job < 1) wg_per_job = 1;
-        const long long n_blocks = ((long long)M + 31) / 32;
-        if (wg_per_job > n_blocks) wg_per_job = (int)n_blocks;
-        hipLaunchKernelGGL(train16_dw_kernel, dim3(t->n_jobs * wg_per_job), dim3(kWaves * 64), 0, st, t->jobs, wg_per_job,
+        // one resident workgroup per CU (128 accumulator registers per lane): more workgroups would only run in a
+        // second round and add their 256 KB of gradient atomics each; the jobs share them by cost (tables_for)
+        hipLaunchKernelGGL(train16_dw_kernel, dim3(t->n_wg), dim3(kWaves * 64), 0, st, t->jobs, t->n_jobs,
                            stash_tiles, (const uint4 *)grad, x, M, P, F, C_in, P == 63 ? 3 : 4, (float *const *)g_dev);
     }
     ZEST_RETURN_LAUNCH("zest_mlp_train16_bwd");

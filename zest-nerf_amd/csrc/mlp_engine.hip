@@ -83,6 +83,15 @@ __global__ __launch_bounds__(kMlpWaves * 64, kMlpWaves / 4) void mlp_engine_kern
             const float *xrow = x + (size_t)(valid ? m : 0) * C_in;
             load_pe_operand<EP, NT_PTS == 4 ? 3 : 4, 10, NT_PTS / 2>(xrow, valid, grp, pts[cb]);
             if (MOD) load_feat_operand<EP, NT_FEAT / 2>(xrow + P, F, valid, grp, feat[cb]);
+            if constexpr (TRAIN) {          // the encoder's operands go to the stash too: inputs of the weight kernel
+                uint4 *st = stash_tiles + (((long long)pass * kMlpWaves + wave) * kStashTiles * CB + cb) * 64 + lane;
+#pragma unroll
+                for (int k = 0; k < NT_PTS / 2; k++) st[(size_t)(kStashPts + k) * CB * 64] = __builtin_bit_cast(uint4, pts[cb].t[0][k]);
+                if (MOD) {
+#pragma unroll
+                    for (int k = 0; k < NT_FEAT / 2; k++) st[(size_t)(kStashFeat + k) * CB * 64] = __builtin_bit_cast(uint4, feat[cb].t[0][k]);
+                }
+            }
         }
         auto views_fn = [&](OpArr<1, NP> (&views)[CB]) {
 #pragma unroll
@@ -90,6 +99,9 @@ __global__ __launch_bounds__(kMlpWaves * 64, kMlpWaves / 4) void mlp_engine_kern
                 const long long m = m_base + 16 * cb + col;
                 const bool valid = m < M;
                 load_pe_operand<EP, 3, 4, 1>(x + (size_t)(valid ? m : 0) * C_in + P + F, valid, grp, views[cb]);
+                if constexpr (TRAIN)
+                    stash_tiles[((((long long)pass * kMlpWaves + wave) * kStashTiles + kStashViews) * CB + cb) * 64 + lane] =
+                        __builtin_bit_cast(uint4, views[cb].t[0][0]);
             }
         };
         f32x4 headt[CB], rgbt[CB];

@@ -145,7 +145,8 @@ constexpr int bwd_stream_units(int nt_pts, int nt_feat) {
 // One weight-gradient job of the training path: (op's output positions) x (a chunk of <= 256 input positions)
 struct DwJob {
     int32_t out_tile0, n_out_tiles;      // gradient-stash tiles (k-tiles of 32 output positions)
-    int32_t in_kind;                     // 0: activation-stash tiles, 1: point operand (from x), 2: feature operand, 3: direction operand
+    int32_t in_kind;                     // which operand: 0 a layer's output, 1 points, 2 features, 3 directions - all are
+                                         // activation-stash tiles from in_tile0 on (the encoder's at kDwStash*)
     int32_t in_tile0, n_in_tiles;
     int32_t ld, col0, want_bias;
     int32_t wg0, n_wg;                   // workgroups of the weight kernel that share this job (set per device at upload)
@@ -155,6 +156,8 @@ struct DwJob {
 // stash tile indices of the gradient stash (work buffer): d pre-activation of trunk layer l: 8 l + kt;
 // feature_linear 64 + kt; view layer 72 + kt; head tile 76; rgb tile 77; modulation 78 + kt
 constexpr int kGradTiles = 86;
+// activation-stash tiles of the encoder's operands (mlp_train16.h kStashPts / kStashFeat / kStashViews)
+constexpr int kDwStashPts = 76, kDwStashFeat = 79, kDwStashViews = 81;
 int build_dw_jobs(const zest_mlp_desc &d, std::vector<DwJob> *jobs, const char **err);
 
 // Builds the plan; returns false (with *err set) for shapes the kernels do not cover.

@@ -409,15 +409,15 @@ int build_dw_jobs(const zest_mlp_desc &d, std::vector<DwJob> *jobs, const char *
     };
     for (int l = 0; l < 8; l++) {
         const int ld = l == 0 ? d.in_ch_pts : (l == 5 ? kW + d.in_ch_pts : kW);
-        if (l == 0 || l == 5) add(l, 8 * l, 8, 1, 0, kp, ld, 0, l == 0, &p.map_pts);
+        if (l == 0 || l == 5) add(l, 8 * l, 8, 1, kDwStashPts, kp, ld, 0, l == 0, &p.map_pts);
         if (l > 0) add(l, 8 * l, 8, 0, 8 * (l - 1), 8, ld, l == 5 ? d.in_ch_pts : 0, 1, nullptr);
     }
     add(8, 76, 1, 0, 56, 8, kW, 0, 1, nullptr);                       // heads <- h7
     add(9, 64, 8, 0, 56, 8, kW, 0, 1, nullptr);                       // feature_linear <- h7
     add(10, 72, 4, 0, 64, 8, kW + d.in_ch_views, 0, 1, nullptr);      // view layer <- feature_linear output
-    add(10, 72, 4, 3, 0, 1, kW + d.in_ch_views, kW, 0, &p.map_views); //            <- direction encoding
+    add(10, 72, 4, 3, kDwStashViews, 1, kW + d.in_ch_views, kW, 0, &p.map_views);   //   <- direction encoding
     add(11, 77, 1, 0, 72, 4, kW / 2, 0, 1, nullptr);                  // rgb <- view layer
-    if (mod) add(100, 78, 8, 2, 0, kf, d.in_ch_feat, 0, 1, &p.map_feat);   // pts_bias <- features
+    if (mod) add(100, 78, 8, 2, kDwStashFeat, kf, d.in_ch_feat, 0, 1, &p.map_feat);   // pts_bias <- features
     return (int)jobs->size();
 }
 

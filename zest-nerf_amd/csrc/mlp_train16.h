@@ -12,7 +12,11 @@
 //   masks [kStashMasks][2][64 lanes] x 8 B    bit 8 * k-tile + element = "output was > 0"
 #pragma once
 namespace zest {
-constexpr int kStashTiles = 76;       // 8 trunk layers x 8 k-tiles, feature_linear 8, view layer 4
+// 8 trunk layers x 8 k-tiles, feature_linear 8, view layer 4; then the encoder's operands as the forward pass
+// built them (the weight kernel contracts them like any other layer input): points (up to 3 k-tiles), features
+// (up to 2), directions (1)
+constexpr int kStashTiles = 82;
+constexpr int kStashPts = 76, kStashFeat = 79, kStashViews = 81;
 constexpr int kStashMasks = 9;        // 8 trunk layers, view layer
 constexpr int kTrainBlock = 32;       // samples per block
 inline long long train_blocks(long long M) { return (M + 255) / 256 * 8; }

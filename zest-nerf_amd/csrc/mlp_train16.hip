@@ -399,7 +399,14 @@ __global__ __launch_bounds__(kWaves * 64, kWaves / 4) void train16_dw_kernel(
     const DwJob *__restrict__ jobs, int n_jobs, const uint4 *__restrict__ stash, const uint4 *__restrict__ grad,
     const float *__restrict__ x, int M, int P, int F, int C_in, int pts_c, float *const *__restrict__ g_params) {
     constexpr int CB = 2;
-    __shared__ __attribute__((aligned(16))) char img[2][2][kImgBytes];      // [buffer][0: out (gradient), 1: in][...]
+    // An iteration of the main loop covers NB blocks of 32 samples: its cost is mostly fixed (stage -> rendezvous ->
+    // transposing reads -> MFMA chain, about 2 us with one block), so two blocks per iteration halve it per sample.
+#ifndef ZEST_DW_BLOCKS
+#define ZEST_DW_BLOCKS 2
+#endif
+    constexpr int NB = ZEST_DW_BLOCKS;
+    __shared__ __attribute__((aligned(16))) char img[2][2][NB * kImgBytes];   // [buffer][0: out (gradient), 1: in][sample row][...]
+    static_assert(sizeof(img) <= 160 * 1024, "LDS");
     // jobs own runs of workgroups in proportion to the tiles they stream per block (tables_for)
     int ji = 0;
     for (int j = 1; j < n_jobs; j++)
@@ -412,7 +419,14 @@ __global__ __launch_bounds__(kWaves * 64, kWaves / 4) void train16_dw_kernel(
     const long long per = (n_blocks + wg_per_job - 1) / wg_per_job;
     const long long b0 = part * per, b1 = min(n_blocks, b0 + per);
     if (b0 >= b1) return;                  // fewer blocks than workgroups (tiny batches): nothing to add
-    const int n_in = job.n_in_tiles, n_out = job.n_out_tiles;
+    // The job's scalars, read once into registers the compiler cannot re-derive from memory: left as `job.x` it
+    // re-loads them with s_load inside the main loop (cheaper than an SGPR to it) - and every such load ends in an
+    // s_waitcnt lgkmcnt(0) that also drains the LDS reads in flight: the loop ran at the pace of scalar-cache
+    // round trips, whatever else it did (each of: the staging, the MFMAs, the rendezvous could be removed without
+    // changing the kernel's 590 us).
+    const int n_in = __builtin_amdgcn_readfirstlane(job.n_in_tiles), n_out = __builtin_amdgcn_readfirstlane(job.n_out_tiles);
+    const int want_bias = __builtin_amdgcn_readfirstlane(job.want_bias);
+    const int out_tile0 = __builtin_amdgcn_readfirstlane(job.out_tile0), in_tile0 = __builtin_amdgcn_readfirstlane(job.in_tile0);
     f32x4 acc[2][16], accb[2];
 #pragma unroll
     for (int rt = 0; rt < 2; rt++) {
@@ -424,7 +438,7 @@ __global__ __launch_bounds__(kWaves * 64, kWaves / 4) void train16_dw_kernel(
     const unsigned img0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)&img[0][0][0];
     // items = (tile, column block) of a block: a wave takes items wave, wave + 8, ... (at most 4); the tiles of
     // block b + 1 are requested before block b is computed, so their HBM latency hides behind the MFMAs
-    const int items = (n_out + (job.in_kind == 0 ? n_in : 0)) * CB;
+    const int items = (n_out + n_in) * CB;
     auto fetch_item = [&](long long b, int it) {
 #ifdef ZEST_DW_EXP_NO_LOADS            // timing experiment only: every block reads the first one again (L2 hits)
         b = b0;
@@ -432,92 +446,91 @@ __global__ __launch_bounds__(kWaves * 64, kWaves / 4) void train16_dw_kernel(
         const int t = it / CB, cb = it % CB;
         const bool is_out = t < n_out;
         const int kt = is_out ? t : t - n_out;
-        return is_out ? grad[(((size_t)b * kGradTiles + job.out_tile0 + kt) * CB + cb) * 64 + lane]
-                      : stash[(((size_t)b * kStashTiles + job.in_tile0 + kt) * CB + cb) * 64 + lane];
+        return is_out ? grad[(((size_t)b * kGradTiles + out_tile0 + kt) * CB + cb) * 64 + lane]
+                      : stash[(((size_t)b * kStashTiles + in_tile0 + kt) * CB + cb) * 64 + lane];
     };
-    // Operands that are not in the stash (the encoder's: points, features, directions) are rebuilt from the rows of
-    // x: wave w takes column block w % CB, k-tile w / CB (at most 3 k-tiles: six waves side by side), and requests
-    // its eight values one block ahead of their use, like the tiles.
-#ifndef ZEST_DW_EXP_NO_REBUILD         // (defined: timing experiment only)
-    const bool rebuild = job.in_kind != 0 && wave < CB * n_in;
-#else
-    const bool rebuild = false;
-#endif
-    const int rb_cb = wave % CB, rb_kt = wave / CB;
-    float xraw[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    auto fetch_raw = [&](long long b) {
-        const long long m = b * 32 + 16 * rb_cb + col;
-        const bool valid = m < M;
-        const float *xr = x + (size_t)(valid ? m : 0) * C_in;
-        if (job.in_kind == 1) {
-            if (pts_c == 3) load_pe_tile_raw<3, 10>(xr, valid, grp, rb_kt, xraw);
-            else load_pe_tile_raw<4, 10>(xr, valid, grp, rb_kt, xraw);
-        } else if (job.in_kind == 2) {
-            load_feat_tile_raw(xr + P, F, valid, grp, rb_kt, xraw);
-        } else {
-            load_pe_tile_raw<3, 4>(xr + P + F, valid, grp, rb_kt, xraw);
-        }
-    };
-    if (rebuild) fetch_raw(b0);
     // tiles of blocks b .. b + kDwAhead - 1: requested kDwAhead blocks ahead of their use (HBM latency under the
     // load of 255 workgroups streaming is several microseconds; a block is ~2 us of work)
 #ifndef ZEST_DW_AHEAD
-#define ZEST_DW_AHEAD 2
+#define ZEST_DW_AHEAD 1        // iterations ahead: with two blocks per iteration the same two blocks as before
 #endif
-    constexpr int kDwAhead = ZEST_DW_AHEAD;
-    uint4 pre[kDwAhead][4];
+    constexpr int kDwAhead = ZEST_DW_AHEAD;          // iterations (of NB blocks) ahead
+    uint4 pre[kDwAhead][NB][4];
+    // a block past the end of this workgroup's range contributes nothing: its gradient tiles are zero
+    auto fetch_or_zero = [&](long long b, int it) { return b < b1 ? fetch_item(b, it) : uint4{0u, 0u, 0u, 0u}; };
 #pragma unroll
     for (int d = 0; d < kDwAhead; d++)
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-            if (b0 + d < b1 && wave + 8 * i < items) pre[d][i] = fetch_item(b0 + d, wave + 8 * i);
-    for (long long b = b0; b < b1; b++) {
-        const int buf = (int)((b - b0) & 1);
+        for (int sb = 0; sb < NB; sb++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (wave + 8 * i < items) pre[d][sb][i] = fetch_or_zero(b0 + d * NB + sb, wave + 8 * i);
+    int buf = 0;
+    for (long long b = b0; b < b1; b += NB, buf ^= 1) {
         char *im_out = img[buf][0], *im_in = img[buf][1];
-        // ---- stage the block's tiles: image row = sample, 16 B at position 8 g of the k-tile
+        // ---- stage the blocks' tiles: image row = sample, 16 B at position 8 g of the k-tile
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int it = wave + 8 * i;
-            if (it >= items) continue;
-            const int t = it / CB, cb = it % CB;
-            const bool is_out = t < n_out;
-            const int kt = is_out ? t : t - n_out;
-            *reinterpret_cast<uint4 *>((is_out ? im_out : im_in) + (16 * cb + col) * kImgStride + kt * 64 + grp * 16) = pre[0][i];
+        for (int sb = 0; sb < NB; sb++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int it = wave + 8 * i;
+                if (it >= items) continue;
+                const int t = it / CB, cb = it % CB;
+                const bool is_out = t < n_out;
+                const int kt = is_out ? t : t - n_out;
+#ifdef ZEST_DW_EXP_NO_STAGE            // timing experiment only: the tiles never enter LDS (their loads become dead code)
+                if (b == b0)
+#endif
+                *reinterpret_cast<uint4 *>((is_out ? im_out : im_in) + (32 * sb + 16 * cb + col) * kImgStride + kt * 64 + grp * 16) =
+                    pre[0][sb][i];
+            }
         }
-        // operands that are not in the stash were requested from the rows of x one block ahead (xraw): round, pack, store
-        if (rebuild) {
-            OpArr<1, 1> o;
-            store_tile<EP>(xraw, o, 0);
-            *reinterpret_cast<uint4 *>(im_in + (16 * rb_cb + col) * kImgStride + rb_kt * 64 + grp * 16) = __builtin_bit_cast(uint4, o.t[0][0]);
-        }
+#ifndef ZEST_DW_EXP_NO_SYNC             // (defined: timing experiment only, results are wrong)
         __syncthreads();
+#endif
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int sb = 0; sb < NB; sb++) {
 #pragma unroll
-            for (int d = 0; d + 1 < kDwAhead; d++) pre[d][i] = pre[d + 1][i];
-            if (b + kDwAhead < b1 && wave + 8 * i < items) pre[kDwAhead - 1][i] = fetch_item(b + kDwAhead, wave + 8 * i);
+            for (int i = 0; i < 4; i++) {
+#pragma unroll
+                for (int d = 0; d + 1 < kDwAhead; d++) pre[d][sb][i] = pre[d + 1][sb][i];
+                if (wave + 8 * i < items) pre[kDwAhead - 1][sb][i] = fetch_or_zero(b + (long long)kDwAhead * NB + sb, wave + 8 * i);
+            }
         }
-        if (rebuild && b + 1 < b1) fetch_raw(b + 1);
 #ifdef ZEST_DW_EXP_NO_MFMA             // timing experiment only
         if (b == b0 && wave < n_out) {
 #else
         if (wave < n_out) {
 #endif
-            const unsigned a_out = img0 + (unsigned)(buf * 2) * kImgBytes, a_in = a_out + kImgBytes;
-            bf16x8 A[2];
 #pragma unroll
-            for (int rt = 0; rt < 2; rt++) A[rt] = tr_operand(a_out, 32 * wave + 16 * rt, lane);
+            for (int sb = 0; sb < NB; sb++) {
+                const unsigned a_out = img0 + (unsigned)(buf * 2) * (NB * kImgBytes) + (unsigned)sb * kImgBytes;
+                const unsigned a_in = a_out + NB * kImgBytes;
+                bf16x8 A[2];
 #pragma unroll
-            for (int ct = 0; ct < 16; ct++) {
-                if (ct < 2 * n_in) {
-                    const bf16x8 B = tr_operand(a_in, 16 * ct, lane);
+                for (int rt = 0; rt < 2; rt++) A[rt] = tr_operand(a_out, 32 * wave + 16 * rt, lane);
+                // All 16 column tiles, whatever the job's number of input k-tiles: straight-line code, so the
+                // transposing reads run ahead of the MFMAs (with a test of ct against n_in in front of each pair of
+                // reads hipcc waited for every read right behind it: 16 exposed LDS latencies per block, the kernel's
+                // bottleneck).  Tiles past 2 n_in multiply whatever the image holds there into accumulators that are
+                // never written out.
+                // The reads are pipelined by hand, in source order, kAheadB column tiles ahead of the MFMAs that use them.
+                constexpr int kAheadB = 3;
+                bf16x8 Bq[kAheadB];
+#pragma unroll
+                for (int ct = 0; ct < kAheadB; ct++) Bq[ct] = tr_operand(a_in, 16 * ct, lane);
+#pragma unroll
+                for (int ct = 0; ct < 16; ct++) {
+                    const bf16x8 B = Bq[ct % kAheadB];
+                    if (ct + kAheadB < 16) Bq[ct % kAheadB] = tr_operand(a_in, 16 * (ct + kAheadB), lane);
 #pragma unroll
                     for (int rt = 0; rt < 2; rt++) acc[rt][ct] = mfma16<EP>(A[rt], B, acc[rt][ct]);
-                }
-            }
-            if (job.want_bias) {
+                    __builtin_amdgcn_sched_barrier(0);      // keep the read-ahead distance (hipcc otherwise sinks each read
+                }                                           // to just in front of its use to save four registers)
+                if (want_bias) {
 #pragma unroll
-                for (int rt = 0; rt < 2; rt++) accb[rt] = mfma16<EP>(A[rt], ones, accb[rt]);
+                    for (int rt = 0; rt < 2; rt++) accb[rt] = mfma16<EP>(A[rt], ones, accb[rt]);
+                }
             }
         }
     }
@@ -570,33 +583,18 @@ TrainTables *tables_for(const zest_mlp_desc &d) {
         return nullptr;
     }
     t->n_jobs = (int)jobs.size();
-    {   // Workgroups per job.  The time of a job is set by its number of blocks per workgroup: an iteration costs
-        // about the same 2 us whether it stages 5 tiles or 16 (latency of the stage -> rendezvous -> transposing
-        // reads -> MFMA chain, not bandwidth), so a split in proportion to the tiles a job streams leaves the light
-        // jobs (rgb: 5 tiles, 7 workgroups) running 1.6x longer than an even one (measured: 990 us against 600).
-        // The jobs that rebuild an operand from the rows of x pay ~20 % more per iteration (4-byte gathers: one
-        // cache-line request per lane and element) and get that many more workgroups.
+    {   // Workgroups per job: an even split of the CUs.  The time of a job is set by its number of blocks per
+        // workgroup, hardly by the tiles it streams per block (an iteration costs about the same whether it stages
+        // 5 tiles or 16), so a split in proportion to the tiles leaves the light jobs (rgb: 5 tiles, 7 workgroups)
+        // running 1.6x longer than the even one (measured: 990 us against 600).
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
             cus = 256;
         const int nj = t->n_jobs;
         if (cus < nj) cus = nj;
-        std::vector<int> cost(nj), wgs(nj);
-        int total = 0, given = 0;
-        for (int j = 0; j < nj; j++) total += cost[j] = jobs[j].in_kind != 0 ? 12 : 10;
-        for (int j = 0; j < nj; j++) given += wgs[j] = std::max(1, (int)((long long)cus * cost[j] / total));
-        while (given != cus) {          // rounding remainder: to the job with the most cost per workgroup / from the one with the least
-            int pick = -1;
-            for (int j = 0; j < nj; j++) {
-                if (given > cus && wgs[j] <= 1) continue;
-                if (pick < 0) { pick = j; continue; }
-                const long long a = (long long)cost[j] * wgs[pick], b = (long long)cost[pick] * wgs[j];
-                if (given < cus ? a > b : a < b) pick = j;
-            }
-            if (given < cus) wgs[pick]++, given++;
-            else wgs[pick]--, given--;
-        }
+        std::vector<int> wgs(nj);
+        for (int j = 0; j < nj; j++) wgs[j] = cus / nj + (j < cus % nj ? 1 : 0);
         for (int j = 0, w0 = 0; j < nj; j++) jobs[j].wg0 = w0, jobs[j].n_wg = wgs[j], w0 += wgs[j];
         t->n_wg = cus;
     }

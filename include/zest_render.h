@@ -279,15 +279,16 @@ int zest_mlp_train_bwd(const zest_mlp_desc *desc, const float *const *params, co
 
 /* ---- MLP training path, bf16 operands on the MFMA engine (hand-written forward AND backward) ----
  * The fast training mode ('v0' nets).  Forward: the inference engine kernel, which additionally
- * stashes every layer's output tiles (bf16, 4.9 KB per sample) and ReLU masks.  Backward: a data
- * kernel that walks the transposed weight stream on the same engine (gradient tiles to `work`,
- * point-encoding gradients into g_x), a modulation kernel (d pts_bias input = feature columns of g_x)
- * and a weight-gradient kernel that contracts the stash tiles over the samples with transposing LDS
- * reads; fp32 accumulation everywhere, fp32 gradients out.
+ * stashes every layer's output tiles and the encoder's operand tiles (bf16, 5.2 KB per sample) and
+ * ReLU masks.  Backward: a data kernel that walks the transposed weight stream on the same engine
+ * (gradient tiles to `work`, point-encoding gradients into g_x), a modulation kernel (d pts_bias input
+ * = feature columns of g_x) and a weight-gradient kernel that contracts the stash tiles over the
+ * samples with transposing LDS reads (per-workgroup partial sums to `work`, then a reduce kernel);
+ * fp32 accumulation everywhere, fp32 gradients out, bit-reproducible from run to run.
  *   packed_fwd: zest_mlp_pack(..., ZEST_PREC_BF16); packed_bwd: zest_mlp_train16_pack (same params).
  *   stash / work: caller-owned, zest_mlp_train16_stash_bytes / _work_bytes; the forward call's stash
  *   and out go unchanged to the backward call.  g_x [M, C_in] and every g_params[i] must be ZERO on
- *   entry (gradients are accumulated with float atomics); the direction columns of g_x stay zero.
+ *   entry (gradients are added to them); the direction columns of g_x stay zero.
  *   stages: bit 0 data kernel, bit 1 modulation kernel, bit 2 weight kernel (7 = all; tests run them apart). */
 size_t zest_mlp_train16_stash_bytes(const zest_mlp_desc *desc, int M);
 size_t zest_mlp_train16_work_bytes(const zest_mlp_desc *desc, int M);

@@ -45,6 +45,7 @@ struct Sizes {
     long long blocks;
     size_t tile_bytes, mask_bytes, grad_bytes, side_bytes;
 };
+constexpr size_t kPtrTableBytes = 256;          // 2 * ZEST_P_COUNT gradient pointers, padded
 Sizes sizes_of(int M) {
     Sizes s;
     s.blocks = train_blocks(M);
@@ -380,6 +381,7 @@ __global__ __launch_bounds__(256) void train16_finish_kernel(
 }
 
 // ------------------------------------------------------------------------------ weight kernel
+constexpr int kDwSlots = 34;                 // accumulators of a wave of the weight kernel: 2 row tiles x 16 column tiles + 2 bias
 constexpr int kImgStride = 528;              // bytes per sample row of an LDS image: 256 positions x 2 B + 16 (bank spread)
 constexpr int kImgBytes = 32 * kImgStride;
 
@@ -397,7 +399,7 @@ __device__ __forceinline__ bf16x8 tr_operand(unsigned img_addr, int p0, int lane
 
 __global__ __launch_bounds__(kWaves * 64, kWaves / 4) void train16_dw_kernel(
     const DwJob *__restrict__ jobs, int n_jobs, const uint4 *__restrict__ stash, const uint4 *__restrict__ grad,
-    const float *__restrict__ x, int M, int P, int F, int C_in, int pts_c, float *const *__restrict__ g_params) {
+    int M, float4 *__restrict__ partial) {
     constexpr int CB = 2;
     // An iteration of the main loop covers NB blocks of 32 samples: its cost is mostly fixed (stage -> rendezvous ->
     // transposing reads -> MFMA chain, about 2 us with one block), so two blocks per iteration halve it per sample.
@@ -418,7 +420,7 @@ __global__ __launch_bounds__(kWaves * 64, kWaves / 4) void train16_dw_kernel(
     const long long n_blocks = ((long long)M + 31) / 32;
     const long long per = (n_blocks + wg_per_job - 1) / wg_per_job;
     const long long b0 = part * per, b1 = min(n_blocks, b0 + per);
-    if (b0 >= b1) return;                  // fewer blocks than workgroups (tiny batches): nothing to add
+    // (a workgroup without blocks - tiny batches - still writes its slice of the partial sums: zeros)
     // The job's scalars, read once into registers the compiler cannot re-derive from memory: left as `job.x` it
     // re-loads them with s_load inside the main loop (cheaper than an SGPR to it) - and every such load ends in an
     // s_waitcnt lgkmcnt(0) that also drains the LDS reads in flight: the loop ran at the pace of scalar-cache
@@ -534,28 +536,56 @@ __global__ __launch_bounds__(kWaves * 64, kWaves / 4) void train16_dw_kernel(
             }
         }
     }
+    if (wave >= n_out) return;
+    // ---- this workgroup's slice of the sums goes to its own 272 KB of the partial buffer, accumulator by
+    // accumulator (1 KiB per wave-instruction); train16_dw_reduce_kernel adds the slices of a job and scatters
+    // the totals into the fp32 gradients.  (Float atomics from all 256 workgroups straight into the gradients -
+    // 16.8 M of them - cost 88 of this kernel's 425 us.)
+    float4 *mine = partial + ((size_t)blockIdx.x * kWaves + wave) * kDwSlots * 64 + lane;
 #ifdef ZEST_DW_EXP_NO_ATOMICS          // timing experiment only: results are wrong
     if (acc[0][0][0] != 123456.0f) return;
 #endif
-    if (wave >= n_out) return;
-    // ---- add this workgroup's slice to the fp32 gradients: accumulator (rt, ct): rows = output positions
-    // 32 wave + 16 rt + 4 g + r, column = input position 16 ct + col
 #pragma unroll
-    for (int rt = 0; rt < 2; rt++)
+    for (int rt = 0; rt < 2; rt++) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int po = 32 * wave + 16 * rt + 4 * grp + r;
-            const int slot = job.out_slot[po], row = job.out_row[po];
-            if (slot < 0) continue;
-            float *gw = g_params[2 * slot] + (size_t)row * job.ld + job.col0;
+        for (int ct = 0; ct < 16; ct++)
+            mine[(rt * 16 + ct) * 64] = make_float4(acc[rt][ct][0], acc[rt][ct][1], acc[rt][ct][2], acc[rt][ct][3]);
+        mine[(32 + rt) * 64] = make_float4(accb[rt][0], accb[rt][1], accb[rt][2], accb[rt][3]);
+    }
+}
+
+// One thread per (job, wave, accumulator, lane): the sum over the job's workgroups of that accumulator's four values,
+// added to the fp32 gradients through the job's position maps.  Every gradient element belongs to exactly one
+// accumulator element of one job (the two jobs of the skip layer and of the view layer own different columns), so
+// plain read-modify-write is enough - and the result does not depend on the order workgroups finish in.
+__global__ __launch_bounds__(256) void train16_dw_reduce_kernel(const DwJob *__restrict__ jobs, int n_jobs,
+                                                                const float4 *__restrict__ partial,
+                                                                float *const *__restrict__ g_params) {
+    const int per_job = kWaves * kDwSlots * 64;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_jobs * per_job) return;
+    const DwJob &job = jobs[i / per_job];
+    const int r_ = i % per_job, wave = r_ / (kDwSlots * 64), slot = r_ / 64 % kDwSlots, lane = r_ % 64;
+    const int col = lane & 15, grp = lane >> 4;
+    const bool is_bias = slot >= 32;
+    const int rt = is_bias ? slot - 32 : slot / 16, ct = slot % 16;
+    if (wave >= job.n_out_tiles || (is_bias ? !job.want_bias || col != 0 : ct >= 2 * job.n_in_tiles)) return;
+    const int ci = is_bias ? 0 : job.in_col[16 * ct + col];
+    if (ci < 0) return;
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int w = 0; w < job.n_wg; w++) {
+        const float4 v = partial[((size_t)(job.wg0 + w) * kWaves + wave) * kDwSlots * 64 + slot * 64 + lane];
+        sum.x += v.x, sum.y += v.y, sum.z += v.z, sum.w += v.w;
+    }
+    const float vals[4] = {sum.x, sum.y, sum.z, sum.w};
 #pragma unroll
-            for (int ct = 0; ct < 16; ct++) {
-                if (ct >= 2 * n_in) continue;
-                const int ci = job.in_col[16 * ct + col];
-                if (ci >= 0) atomicAdd(gw + ci, acc[rt][ct][r]);
-            }
-            if (job.want_bias && col == 0) atomicAdd(g_params[2 * slot + 1] + row, accb[rt][r]);
-        }
+    for (int r = 0; r < 4; r++) {
+        const int po = 32 * wave + 16 * rt + 4 * grp + r;
+        const int ps = job.out_slot[po], row = job.out_row[po];
+        if (ps < 0) continue;
+        if (is_bias) g_params[2 * ps + 1][row] += vals[r];
+        else g_params[2 * ps][(size_t)row * job.ld + job.col0 + ci] += vals[r];
+    }
 }
 
 // ------------------------------------------------------------------------------ host side
@@ -623,6 +653,11 @@ int cu_count() {
         cus = 256;
     return cus;
 }
+// partial sums of the weight kernel: one slice per workgroup (one workgroup per CU, at least one per job: 16 jobs at most)
+size_t dw_partial_bytes() {
+    const int cus = cu_count();
+    return (size_t)(cus < 16 ? 16 : cus) * kWaves * kDwSlots * 1024;
+}
 
 }  // namespace
 
@@ -634,7 +669,7 @@ extern "C" size_t zest_mlp_train16_stash_bytes(const zest_mlp_desc *desc, int M)
 extern "C" size_t zest_mlp_train16_work_bytes(const zest_mlp_desc *desc, int M) {
     if (!desc || M <= 0) return 0;
     const Sizes s = sizes_of(M);
-    return s.grad_bytes + s.side_bytes + 2 * ZEST_P_COUNT * sizeof(float *);
+    return s.grad_bytes + s.side_bytes + kPtrTableBytes + dw_partial_bytes();
 }
 extern "C" size_t zest_mlp_train16_packed_bytes(const zest_mlp_desc *desc) { return desc ? zest::bwd_stream_bytes(*desc) : 0; }
 
@@ -727,9 +762,12 @@ extern "C" int zest_mlp_train16_bwd(const zest_mlp_desc *desc, const void *packe
             return (int)e;
         }
         // one resident workgroup per CU (128 accumulator registers per lane): more workgroups would only run in a
-        // second round and add their 256 KB of gradient atomics each; the jobs share them by cost (tables_for)
+        // second round and add their 272 KB of partial sums each
+        float4 *partial = (float4 *)((char *)work + s.grad_bytes + s.side_bytes + kPtrTableBytes);
         hipLaunchKernelGGL(train16_dw_kernel, dim3(t->n_wg), dim3(kWaves * 64), 0, st, t->jobs, t->n_jobs,
-                           stash_tiles, (const uint4 *)grad, x, M, P, F, C_in, P == 63 ? 3 : 4, (float *const *)g_dev);
+                           stash_tiles, (const uint4 *)grad, M, partial);
+        hipLaunchKernelGGL(train16_dw_reduce_kernel, dim3(zest_div_up(t->n_jobs * kWaves * kDwSlots * 64, 256)), dim3(256), 0, st,
+                           t->jobs, t->n_jobs, (const float4 *)partial, (float *const *)g_dev);
     }
     ZEST_RETURN_LAUNCH("zest_mlp_train16_bwd");
 }

@@ -299,19 +299,22 @@ __global__ __launch_bounds__(256) void train16_finish_kernel(
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int c = map_pts[32 * jb + 16 * rt + 4 * grp + r];
+#ifdef ZEST_FIN_EXP_NO_GX               // timing experiment only
+                    if (c >= 0 && v[r] == 123456.0f) gx_row[cb][c] = v[r];
+#else
                     if (c >= 0) gx_row[cb][c] = v[r];
+#endif
                 }
             }
     if constexpr (KF > 0) {
         const uint4 *sblk = stash + (size_t)block * kStashTiles * CB * 64;
         uint4 *gblk = grad + (size_t)block * kGradTiles * CB * 64;
-        OpArr<KF> feat[CB];
+        OpArr<KF> feat[CB];           // the feature operand as the forward pass built it (stash tiles kStashFeat ..)
 #pragma unroll
-        for (int cb = 0; cb < CB; cb++) {
-            const long long m = block * 32 + 16 * cb + col;
-            const bool valid = m < M;
-            load_feat_operand<EP, KF>(x + (size_t)(valid ? m : 0) * C_in + P, F, valid, grp, feat[cb]);
-        }
+        for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+            for (int k = 0; k < KF; k++)
+                feat[cb].t[0][k] = __builtin_bit_cast(bf16x8, sblk[((kStashFeat + k) * CB + cb) * 64 + lane]);
         OpArr<8> dm[CB];
 #pragma unroll
         for (int jb = 0; jb < 8; jb++) {
@@ -373,7 +376,11 @@ __global__ __launch_bounds__(256) void train16_finish_kernel(
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         const int c = map_feat[32 * jb + 16 * rt + 4 * grp + r];
+#ifdef ZEST_FIN_EXP_NO_GX               // timing experiment only
+                        if (c >= 0 && acc[rt][cb][r] == 123456.0f) gx_row[cb][P + c] = acc[rt][cb][r];
+#else
                         if (c >= 0) gx_row[cb][P + c] = acc[rt][cb][r];
+#endif
                     }
             }
         }

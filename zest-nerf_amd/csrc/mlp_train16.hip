@@ -260,6 +260,25 @@ __global__ __launch_bounds__(kWaves * 64, kWaves / 4) void train16_data_kernel(
     tiles.drain();
 }
 
+// Input column of accumulator row (row tile rt, lane group grp, element r) of row block jb of a transposed encoder
+// operand = the plan's position map (mlp_plan.hip pe_map_acc / feat_map_acc) at position 32 jb + 16 rt + 4 grp + r,
+// in closed form: everything but the lane group is a compile-time constant after unrolling.  (Looked up in the
+// device copies of the maps, every element was a 2-byte global load with a store waiting on it: 48 + 16 exposed
+// round trips per block were most of the finishing kernel's time.)
+template <int C, int L>
+__device__ __forceinline__ int pe_col_of(int jb, int rt, int r, int grp) {
+    const int g = 2 * rt + (grp >> 1), mm = 8 * jb + 4 * (grp & 1) + r;
+    if (mm < (L / 2) * C) return C + 2 * C * (2 * (mm / C) + (g >> 1)) + ((g & 1) ? C : 0) + mm % C;
+    return (mm == (L / 2) * C && g < C) ? g : -1;
+}
+__device__ __forceinline__ int feat_col_of(int jb, int rt, int r, int grp, int V) {
+    const int q = 8 * jb + 4 * rt + grp;                      // quad of four channels
+    if (q == 0) return r;
+    if (q == 2) return 4 + r;
+    const int view = q == 1 ? 0 : (q == 3 ? 1 : q - 2);
+    return view < V ? 8 + 4 * view + r : -1;
+}
+
 // ------------------------------------------------------------------------------ finishing kernel
 // Per block of 32 samples, one wave, everything straight from global memory / L2 (no ring):
 //   * point-encoding gradient: the two side-buffer contributions (layers 5 and 0) are added and scattered
@@ -298,7 +317,7 @@ __global__ __launch_bounds__(256) void train16_finish_kernel(
                 if (!gx_row[cb]) continue;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const int c = map_pts[32 * jb + 16 * rt + 4 * grp + r];
+                    const int c = pe_col_of<NT_PTS == 4 ? 3 : 4, 10>(jb, rt, r, grp);
 #ifdef ZEST_FIN_EXP_NO_GX               // timing experiment only
                     if (c >= 0 && v[r] == 123456.0f) gx_row[cb][c] = v[r];
 #else
@@ -375,7 +394,7 @@ __global__ __launch_bounds__(256) void train16_finish_kernel(
                 for (int rt = 0; rt < 2; rt++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        const int c = map_feat[32 * jb + 16 * rt + 4 * grp + r];
+                        const int c = feat_col_of(jb, rt, r, grp, (F - 8) / 4);
 #ifdef ZEST_FIN_EXP_NO_GX               // timing experiment only
                         if (c >= 0 && acc[rt][cb][r] == 123456.0f) gx_row[cb][P + c] = acc[rt][cb][r];
 #else

@@ -1,8 +1,9 @@
 // MFMA engine for the width-256 NeRF MLP (bf16 / fp16 / split-fp16 operands): activations stay in registers.
 //
-// Orientation: Y^T = W X^T with v_mfma_f32_16x16x32_bf16 (this kernel is limited by board power,
-// not by issue cycles; at identical operand traffic this shape delivered 5-15 % more FLOP/s
-// here than 32x32x16, cf. MI355X_MICROARCH.md "Shape").  A wave owns NB blocks of 32 samples =
+// Orientation: Y^T = W X^T with v_mfma_f32_16x16x32_bf16 (under random data the chip holds a higher clock
+// on this shape: at identical operand traffic it delivered 5-15 % more FLOP/s here than 32x32x16, cf.
+// MI355X_MICROARCH.md "Shape"; its price is issue room - two plain VALU slots per MFMA - so the
+// epilogues count their instructions).  A wave owns NB blocks of 32 samples =
 // 2 NB column blocks of 16: lane l serves sample column l & 15 of every column block, as group
 // g = l >> 4 of four.  The A operand is a pre-packed 1 KiB weight tile (16 output rows x 32
 // k-positions, mlp_plan.h) and feeds one MFMA per column block; the B operand is one k-tile of

@@ -288,6 +288,9 @@ __device__ __forceinline__ int feat_col_of(int jb, int rt, int r, int grp, int V
 //     h_l = pre_l m, so the product is d h_l mask pre_l) becomes gradient tiles 78 .. 85 for the weight kernel,
 //     and d features = Wm^T d m (MFMA with the backward stream's tail) goes to the feature columns of g_x.
 template <int NT_PTS, int NT_FEAT>
+#ifdef ZEST_FIN_WAVES                  // occupancy experiment: cap the registers for this many waves per SIMD
+__attribute__((amdgpu_waves_per_eu(ZEST_FIN_WAVES, ZEST_FIN_WAVES)))
+#endif
 __global__ __launch_bounds__(256) void train16_finish_kernel(
     const float *__restrict__ x, int M, int P, int F, int C_in, const uint4 *__restrict__ bwd_tail,
     const uint4 *__restrict__ stash, uint4 *__restrict__ grad,

@@ -192,3 +192,18 @@ def test_pass_shapes_agree(hip, R, S, mode, monkeypatch):
         got = render_scene(sc, c, maps_only=True, **kw)
         for k in MAP_KEYS:
             close(got[k][0], want[k].numpy(), atol=ATOL, rtol=RTOL, name="%dx%d/%s" % (R, S, k))
+
+
+def test_fp16_activations_saturate_instead_of_overflowing(hip):
+    """fp16 operands: an activation beyond 65504 must saturate (MODE.FP16_OVFL + the packed ReLU), not round to
+    infinity and turn the next layer's sums into NaN.  First-layer weights are scaled until h0 is ~1e6; bf16 (range
+    of fp32) gives the finite reference of what the network computes, fp16 must stay finite too."""
+    zh, inp, desc, _ = _mlp_setup("mlp_static_nomvs")
+    state = {k: G(v).clone() for k, v in inp["state"].items()}
+    state["nerf.pts_linears.0.weight"] *= 3e5
+    tab = zh.param_table(state, desc)
+    x = G(inp["x"])[0]
+    y16 = zh.mlp_fwd(desc, zh.PREC_F16, zh.mlp_pack(desc, zh.PREC_F16, tab), x)
+    yb = zh.mlp_fwd(desc, zh.PREC_BF16, zh.mlp_pack(desc, zh.PREC_BF16, tab), x)
+    assert torch.isfinite(yb).all() and float(yb.abs().max()) > 1e3        # the test does overflow fp16's range
+    assert torch.isfinite(y16).all(), "fp16 activations overflowed to inf / NaN"

@@ -305,6 +305,7 @@ template <int EP, int NT_FEAT_S, bool DYN, int NT_FEAT_D>
 __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_CU / 4) void fused_blocks_kernel(FusedArgs a) {
     constexpr bool MOD_S = NT_FEAT_S > 0, MOD_D = NT_FEAT_D > 0;
     constexpr int NP = ep_parts(EP), CB = fused_cb(EP), BS = 16 * CB;
+    if constexpr (EP == ZEST_PREC_F16) engine_fp16_overflow_clamp();
     constexpr int UNITS_S = stream_units(4, NT_FEAT_S, NP), UNITS_D = DYN ? stream_units(6, NT_FEAT_D, NP) : 0;
     using Ring = RingTiles<kFusedWaves, UNITS_S, UNITS_D>;
     // LDS: weight ring | cameras of both nets | per-lane (z, dist) of the pass's samples | ring flags |

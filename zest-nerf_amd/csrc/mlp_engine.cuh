@@ -419,7 +419,7 @@ __device__ __forceinline__ void store_tile(const float (&v)[8], OpArr<N, ep_part
     }
 }
 
-// ReLU of a bf16 operand tile AFTER rounding, on the packed pairs: a negative bf16 is a negative int16, so
+// ReLU of a 16-bit operand tile AFTER rounding, on the packed pairs: a negative bf16 is a negative int16, so
 // max(x, 0) per 16-bit half is one v_pk_max_i16 for two values where relu in fp32 costs one v_med3_f32 each.
 // Same bits as relu-then-round (rounding keeps the sign; -0 becomes +0 either way).  The engine's issue port
 // is the contended resource (MI355X_MICROARCH.md, row 'vector-instruction ISSUE cost': a 16x16x32 MFMA leaves
@@ -432,11 +432,18 @@ __device__ __forceinline__ unsigned relu_bf16x2(unsigned u) {
     const s16x2_t r = __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, u), s16x2_t{0, 0});
     return __builtin_bit_cast(unsigned, r);
 }
-template <int N>
-__device__ __forceinline__ void store_tile_relu_bf16(const float (&v)[8], OpArr<N, 1> &op, int k) {
-    const uint4 q = make_uint4(relu_bf16x2(pack_bf16(v[0], v[1])), relu_bf16x2(pack_bf16(v[2], v[3])),
-                               relu_bf16x2(pack_bf16(v[4], v[5])), relu_bf16x2(pack_bf16(v[6], v[7])));
+template <int EP, int N>
+__device__ __forceinline__ void store_tile_relu16(const float (&v)[8], OpArr<N, 1> &op, int k) {
+    const uint4 q = make_uint4(relu_bf16x2(pack_pair<EP>(v[0], v[1])), relu_bf16x2(pack_pair<EP>(v[2], v[3])),
+                               relu_bf16x2(pack_pair<EP>(v[4], v[5])), relu_bf16x2(pack_pair<EP>(v[6], v[7])));
     op.t[0][k] = __builtin_bit_cast(bf16x8, q);
+}
+// fp16 operands take the same packed ReLU (a negative fp16 is a negative int16 as well).  What the fp32 ReLU did on
+// top for them - saturate an activation beyond 65504 instead of letting it round to infinity (and NaN one layer
+// later) - is done by the hardware: with MODE.FP16_OVFL set an fp16 result that overflows is clamped to +-65504.
+// The kernels that run the engine on fp16 operands set the bit once at their start (engine_fp16_overflow_clamp).
+__device__ __forceinline__ void engine_fp16_overflow_clamp() {
+    __builtin_amdgcn_s_setreg((0 << 11) | (23 << 6) | 1, 1);        // hwreg(HW_REG_MODE, offset 23 = FP16_OVFL, 1 bit) = 1
 }
 
 #ifndef ZEST_PREFETCH
@@ -481,7 +488,7 @@ __device__ __forceinline__ void engine_layer(const Tiles &tiles, int &unit, bool
     constexpr int NM = MOD ? 2 * NKF : 0, T = NM + 2 * (NKA + NKB);     // tiles per row block
     static_assert(T >= 1, "empty layer");
     // a sink wants the activated fp32 values: only the plain inference layer rounds first
-    constexpr bool kPackedRelu = ZEST_PACKED_RELU && RELU && MODE == 0 && EP == ZEST_PREC_BF16 && __is_same(Sink, NoSink);
+    constexpr bool kPackedRelu = ZEST_PACKED_RELU && RELU && MODE == 0 && EP != ZEST_PREC_F16X3 && __is_same(Sink, NoSink);
     auto preload = [&](RowBlockPre<NP> &p, int u0) {            // u0: the row block's header unit
 #pragma unroll
         for (int rt = 0; rt < 2; rt++) {
@@ -570,7 +577,7 @@ __device__ __forceinline__ void engine_layer(const Tiles &tiles, int &unit, bool
                 if (RELU && !kPackedRelu) v[i] = relu1<EP>(v[i]);
             }
             if (MODE == 0) {
-                if constexpr (kPackedRelu) store_tile_relu_bf16(v, out[cb], jb);
+                if constexpr (kPackedRelu) store_tile_relu16<EP>(v, out[cb], jb);
                 else store_tile<EP>(v, out[cb], jb);
                 sink(sink_id, jb, cb, v);
             } else if (jb == 0) {

@@ -51,6 +51,7 @@ __global__ __launch_bounds__(kMlpWaves * 64, kMlpWaves / 4) void mlp_engine_kern
     int act_out, float *__restrict__ out, uint4 *__restrict__ stash_tiles = nullptr, uint2 *__restrict__ stash_masks = nullptr) {
     constexpr int NP = ep_parts(EP), CB = mlp_cb(EP), UNITS = stream_units(NT_PTS, MOD ? NT_FEAT : 0, NP);
     using Ring = RingTiles<kMlpWaves, UNITS, 0>;
+    if constexpr (EP == ZEST_PREC_F16) engine_fp16_overflow_clamp();
     __shared__ __attribute__((aligned(16))) char lds[kRingUnits * 1024 + 2 * kSlots * 4];
 #ifdef ZEST_RING_FLAGS
     int *ring_flags = reinterpret_cast<int *>(lds + kRingUnits * 1024);

@@ -76,3 +76,33 @@ def test_fused_pass_shapes_for_the_baseline_batches():
     assert zh.fused_pass_shape(600, 300, zh.PREC_BF16, 256) == (0, 250, 3)         # ranges would need a 4th round
     assert zh.fused_pass_shape(2048, 300, zh.PREC_BF16, 256) == (1, 256, 10)       # 10 blocks per ray, carried over passes
     assert zh.fused_pass_shape(0, 64, zh.PREC_BF16, 256)[1:] == (0, 0)
+
+
+def test_fused_pass_shape_covers_every_block_once():
+    """The host's choice (workgroups, rounds) against a restatement of the kernel's block assignment
+    (csrc/fused.cuh: ray ranges [w R / n, (w+1) R / n) x blocks per ray; dense: equal shares of whole passes):
+    every block belongs to exactly one workgroup, no workgroup is empty, `rounds` is the busiest workgroup's pass
+    count, and ray ranges are never taken when they need more rounds than the dense shape."""
+    sys.path.insert(0, os.path.join(ROOT, "zest-nerf_amd"))
+    import random
+    import zest_hip as zh
+    rnd = random.Random(7)
+    cases = [(1, 1, 256), (255, 33, 256), (256, 128, 256), (257, 128, 256), (4097, 192, 304), (5, 1000, 8)]
+    cases += [(rnd.randint(1, 6000), rnd.randint(1, 700), rnd.choice([8, 64, 104, 256, 304])) for _ in range(200)]
+    for prec, bs in ((zh.PREC_BF16, 32), (zh.PREC_F16X3, 16)):
+        for R, S, cus in cases:
+            ranges, n_wg, rounds = zh.fused_pass_shape(R, S, prec, cus)
+            bpr = -(-S // bs)
+            n_blocks = R * bpr
+            assert 1 <= n_wg <= min(cus, n_blocks)
+            if ranges:
+                assert n_wg == min(cus, R)
+                spans = [((w * R // n_wg) * bpr, ((w + 1) * R // n_wg) * bpr) for w in range(n_wg)]
+            else:
+                share = -(-(-(-n_blocks // 8)) // n_wg) * 8
+                spans = [(w * share, min((w + 1) * share, n_blocks)) for w in range(n_wg)]
+            assert spans[0][0] == 0 and spans[-1][1] == n_blocks
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:])) and all(b > a for a, b in spans)
+            assert rounds == max(-(-(b - a) // 8) for a, b in spans)
+            dense_rounds = -(-(-(-n_blocks // 8)) // min(cus, -(-n_blocks // 8)))
+            assert rounds <= dense_rounds or not ranges

@@ -22,6 +22,14 @@ constexpr int mlp_cb(int EP) { return EP == ZEST_PREC_F16X3 ? 1 : 2; }
 //   tiles  [block][kStashTiles][CB][64 lanes] x 16 B      tile = 8 * layer + k-tile (layers 0-7),
 //                                                          64 + k-tile feature_linear, 72 + k-tile view layer
 //   masks  [block][kStashMasks][CB][64 lanes] x 8 B       bit 8 * k-tile + element; 0-7 trunk, 8 view layer
+__device__ __forceinline__ void stash_store(uint4 *p, uint4 q) {
+#ifndef ZEST_STASH_CACHED              // (defined: plain stores, for A/B timing)
+    __builtin_nontemporal_store(__builtin_bit_cast(v4u, q), reinterpret_cast<v4u *>(p));
+#else
+    *p = q;
+#endif
+}
+
 template <int CB>
 struct StashSink {
     uint4 *tiles;
@@ -32,7 +40,9 @@ struct StashSink {
     __device__ __forceinline__ void operator()(int id, int jb, int cb, const float (&v)[8]) const {
         const int t = id < 8 ? 8 * id + jb : (id == 8 ? 64 + jb : 72 + jb);
         uint4 q = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
-        tiles[((block * kStashTiles + t) * CB + cb) * 64 + lane] = q;
+        // streaming stores: the stash (0.7 GB per pass) is read back by later kernels only and must not push the
+        // weight stream and the rows of x out of L2 (forward 285 -> 245 us per 131k samples)
+        stash_store(&tiles[((block * kStashTiles + t) * CB + cb) * 64 + lane], q);
         if (id == 8) return;                                     // feature_linear has no activation
         unsigned bits = 0;
 #pragma unroll
@@ -87,10 +97,10 @@ __global__ __launch_bounds__(kMlpWaves * 64, kMlpWaves / 4) void mlp_engine_kern
             if constexpr (TRAIN) {          // the encoder's operands go to the stash too: inputs of the weight kernel
                 uint4 *st = stash_tiles + (((long long)pass * kMlpWaves + wave) * kStashTiles * CB + cb) * 64 + lane;
 #pragma unroll
-                for (int k = 0; k < NT_PTS / 2; k++) st[(size_t)(kStashPts + k) * CB * 64] = __builtin_bit_cast(uint4, pts[cb].t[0][k]);
+                for (int k = 0; k < NT_PTS / 2; k++) stash_store(&st[(size_t)(kStashPts + k) * CB * 64], __builtin_bit_cast(uint4, pts[cb].t[0][k]));
                 if (MOD) {
 #pragma unroll
-                    for (int k = 0; k < NT_FEAT / 2; k++) st[(size_t)(kStashFeat + k) * CB * 64] = __builtin_bit_cast(uint4, feat[cb].t[0][k]);
+                    for (int k = 0; k < NT_FEAT / 2; k++) stash_store(&st[(size_t)(kStashFeat + k) * CB * 64], __builtin_bit_cast(uint4, feat[cb].t[0][k]));
                 }
             }
         }
@@ -101,8 +111,8 @@ __global__ __launch_bounds__(kMlpWaves * 64, kMlpWaves / 4) void mlp_engine_kern
                 const bool valid = m < M;
                 load_pe_operand<EP, 3, 4, 1>(x + (size_t)(valid ? m : 0) * C_in + P + F, valid, grp, views[cb]);
                 if constexpr (TRAIN)
-                    stash_tiles[((((long long)pass * kMlpWaves + wave) * kStashTiles + kStashViews) * CB + cb) * 64 + lane] =
-                        __builtin_bit_cast(uint4, views[cb].t[0][0]);
+                    stash_store(&stash_tiles[((((long long)pass * kMlpWaves + wave) * kStashTiles + kStashViews) * CB + cb) * 64 + lane],
+                                __builtin_bit_cast(uint4, views[cb].t[0][0]));
             }
         };
         f32x4 headt[CB], rgbt[CB];

@@ -147,7 +147,12 @@ struct MaskEpi {
         const unsigned bits = masked ? ((jb < 4 ? lo[cb] >> (8 * jb) : hi[cb] >> (8 * (jb - 4))) & 0xFFu) : 0xFFu;
 #pragma unroll
         for (int i = 0; i < 8; i++) v[i] = ((bits >> i) & 1u) ? v[i] * m[i] : 0.0f;
+        // streaming store (the gradient stash is read back by the finishing and weight kernels only: data kernel 296 -> 248 us)
+#ifndef ZEST_STASH_CACHED              // (defined: plain stores, for A/B timing)
+        __builtin_nontemporal_store(__builtin_bit_cast(v4u, pack8(v)), reinterpret_cast<v4u *>(&grad[((tile0 + jb) * CB + cb) * 64 + lane]));
+#else
         grad[((tile0 + jb) * CB + cb) * 64 + lane] = pack8(v);
+#endif
     }
     __device__ __forceinline__ void rows(int, int, const float (&)[8]) const {}
 };

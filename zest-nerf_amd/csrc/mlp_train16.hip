@@ -315,12 +315,15 @@ __global__ __launch_bounds__(256) void train16_finish_kernel(
     const int lane = threadIdx.x & 63, col = lane & 15, grp = lane >> 4;
     const long long block = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (block * 32 >= M) return;                                   // wave-uniform
+    // The point and feature columns of the block's 32 rows of g_x are assembled in LDS (row = sample) and written
+    // out as contiguous 256-byte runs: straight from the accumulators every lane writes another row, 64 cache lines
+    // per store instruction (12 % of the kernel).
+    constexpr int kGxStride = 113;                                 // floats per sample row in LDS (>= 84 + 24, odd)
+    __shared__ float gx_lds[4][32 * kGxStride];
+    float *gx_t = gx_lds[threadIdx.x >> 6];
     float *gx_row[CB];
 #pragma unroll
-    for (int cb = 0; cb < CB; cb++) {
-        const long long m = block * 32 + 16 * cb + col;
-        gx_row[cb] = m < M ? g_x + (size_t)m * C_in : nullptr;
-    }
+    for (int cb = 0; cb < CB; cb++) gx_row[cb] = gx_t + (16 * cb + col) * kGxStride;
     // ---- point columns
     const float4 *side = pts_side + (size_t)block * kPtsSideFloat4;
 #pragma unroll
@@ -332,7 +335,6 @@ __global__ __launch_bounds__(256) void train16_finish_kernel(
                 const float4 a = side[(((0 * 3 + jb) * CB + cb) * 2 + rt) * 64 + lane];
                 const float4 b = side[(((1 * 3 + jb) * CB + cb) * 2 + rt) * 64 + lane];
                 const float v[4] = {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
-                if (!gx_row[cb]) continue;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int c = pe_col_of<NT_PTS == 4 ? 3 : 4, 10>(jb, rt, r, grp);
@@ -407,7 +409,6 @@ __global__ __launch_bounds__(256) void train16_finish_kernel(
             }
 #pragma unroll
             for (int cb = 0; cb < CB; cb++) {
-                if (!gx_row[cb]) continue;
 #pragma unroll
                 for (int rt = 0; rt < 2; rt++)
 #pragma unroll
@@ -421,6 +422,13 @@ __global__ __launch_bounds__(256) void train16_finish_kernel(
                     }
             }
         }
+    }
+    // ---- rows out (the LDS operations of a wave execute in order: no barrier between its writes and reads)
+    const int ncol = P + (KF > 0 ? F : 0);
+    for (int r = 0; r < 32; r++) {
+        const long long m = block * 32 + r;
+        if (m >= M) break;                                         // wave-uniform
+        for (int c = lane; c < ncol; c += 64) g_x[(size_t)m * C_in + c] = gx_t[r * kGxStride + c];
     }
 }
 

@@ -5,8 +5,8 @@
   f16    fp16 operands (BASELINE configs[4]): 11 significant bits through 10 layers
   bf16   8 significant bits (configs[1])
 and every instantiation of the fused kernel (static feature tiles 0 / 2 / 4 x dynamic net none /
-plain / with features) in each of them, the 'v2' net, and both pass shapes (ray-aligned passes
-that finish rays in the kernel; dense passes + the combine launch).
+plain / with features) in each of them, the 'v2' net, and both pass shapes (ray ranges that finish
+every ray in the kernel, a ray spanning two passes carried in LDS; dense block shares + the combine launch).
 """
 from types import SimpleNamespace
 

@@ -607,7 +607,11 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
                 o[i] = make_float4(rec[4 * i], rec[4 * i + 1], rec[4 * i + 2], rec[4 * i + 3]);
         }
         }   // g >= 0
+#ifdef ZEST_EXPERIMENT_NO_FINISH       // timing experiment only: no rendezvous, no ray finishing (results are wrong)
+        if (false) {
+#else
         if (ranges) {
+#endif
             // The pass holds consecutive blocks of the workgroup's rays.  After one rendezvous the wave with a
             // ray's first block OF THIS PASS chains that ray's records of this pass (80 B each, in LDS) - onto
             // the sums carried over from the previous pass if the ray began there (then it is wave 0) - and

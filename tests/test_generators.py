@@ -129,16 +129,19 @@ def _generator(args, train_builders=False):
 def test_forward_val_is_chunk_invariant(hip, precision):
     x = _batch(91)
     outs = []
-    for chunk in (256, 384):
-        gen = _generator(_args(chunk=chunk, precision=precision))
+    # chunks of 256 and 384 rays one launch each, and chunks of 128 merged four / three at a time (zest_val_rays)
+    for chunk, merge in ((256, 0), (384, 0), (128, 512), (128, 384)):
+        gen = _generator(_args(chunk=chunk, precision=precision, zest_val_rays=merge))
         res = gen.forward_val(x)
+        assert len(res[1]) == {(256, 0): 4, (384, 0): 3, (128, 512): 2, (128, 384): 4}[(chunk, merge)]
         assert tuple(res[0].shape) == (1, 4, 3, 32, 32)
         outs.append([torch.cat(r) for r in res[1:]])
         assert [tuple(o.shape) for o in outs[-1]] == [(1024, 3), (1024,), (1024, 3), (1024,), (1024, 3), (1024,), (1024,)]
         assert all(torch.isfinite(o).all() for o in outs[-1])
     tol = 1e-5 if precision == 32 else 1e-4
-    for a, b in zip(*outs):
-        assert (a - b).abs().max().item() <= tol * max(1.0, b.abs().max().item())
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert (a - b).abs().max().item() <= tol * max(1.0, b.abs().max().item())
 
 
 @pytest.mark.gpu

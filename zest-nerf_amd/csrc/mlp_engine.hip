@@ -91,7 +91,11 @@ __global__ __launch_bounds__(kMlpWaves * 64, kMlpWaves / 4) void mlp_engine_kern
         for (int cb = 0; cb < CB; cb++) {
             const long long m = m_base + 16 * cb + col;
             const bool valid = m < M;
+#ifdef ZEST_EXP_NO_XGATHER             // timing experiment only: every lane reads row 0 (one cache line set, L1 hits)
+            const float *xrow = x;
+#else
             const float *xrow = x + (size_t)(valid ? m : 0) * C_in;
+#endif
             load_pe_operand<EP, NT_PTS == 4 ? 3 : 4, 10, NT_PTS / 2>(xrow, valid, grp, pts[cb]);
             if (MOD) load_feat_operand<EP, NT_FEAT / 2>(xrow + P, F, valid, grp, feat[cb]);
             if constexpr (TRAIN) {          // the encoder's operands go to the stash too: inputs of the weight kernel

@@ -157,6 +157,31 @@ class Prob2dFn(Function):
         return None, -(g[:, None] * w)
 
 
+class SplitLastFn(Function):
+    """raw [..., C] -> its column groups (contiguous).  Backward is ONE concatenation of the groups' gradients, where
+    autograd's own slice backward launches a zero fill, a strided copy and an accumulation per group (a dozen small
+    kernels per network output in the ZeST training step)."""
+
+    @staticmethod
+    def forward(ctx, raw, *sizes):
+        ctx.sizes = sizes
+        ctx.set_materialize_grads(False)
+        return tuple(p.contiguous() for p in raw.split(sizes, -1))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ref = next(g for g in grads if g is not None)
+        parts = [g if g is not None else ref.new_zeros(*ref.shape[:-1], n) for g, n in zip(grads, ctx.sizes)]
+        return (torch.cat(parts, -1),) + (None,) * len(ctx.sizes)
+
+
+def split_last(raw, sizes):
+    """Column groups of raw's last dimension: under autograd through SplitLastFn, otherwise plain views."""
+    if torch.is_grad_enabled() and raw.requires_grad:
+        return SplitLastFn.apply(raw, *sizes)
+    return raw.split(sizes, -1)
+
+
 def mlp_apply(net, x, time_codes=None, bf16=False):
     """Training forward of a zest networks.MVSNeRF on x [..., C_in] with autograd.  time_codes: the
     frame's latent code for a net with time-code channels (folded into layer 0 / 5 biases with

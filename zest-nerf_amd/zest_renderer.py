@@ -250,8 +250,12 @@ def rendering(args, rays_pts, rays_ndc, depth_candidates, rays_dir,
         ndc = rays_ndc[0].float()
     x_s = encode(vs, volume_feature_static, ndc)
     raw_s = mlp(net_s, x_s, time_codes)
-    raw_rgba = raw_s[..., :4]
-    blend = raw_s[..., 4] if scene_flow else None
+    if scene_flow and train:
+        raw_rgba, blend = za.split_last(raw_s, (4, 1))
+        blend = blend[..., 0]
+    else:
+        raw_rgba = raw_s[..., :4]
+        blend = raw_s[..., 4] if scene_flow else None
     rgb_map, _, _, weights, depth_map, alpha = composite(raw_rgba, noise(), raw_noise_std, white_bkgd)
     F = net_s.in_ch_feat if vs.vol_cl is not None else 0
     input_feat = x_s[None, ..., 63:63 + F] if F else None
@@ -270,13 +274,16 @@ def rendering(args, rays_pts, rays_ndc, depth_candidates, rays_dir,
         return mlp(net_d, encode(vd, volume_feature_dynamic, ndc3, float(t)))
 
     raw_ref = dyn_pass(ndc, ref_frame_idx)
-    sf_prev, sf_post = raw_ref[..., 4:7], raw_ref[..., 7:10]
-    prob_prev, prob_post = raw_ref[..., 10], raw_ref[..., 11]
     if train:
+        # column groups through ONE autograd node per network output (their gradients come back as one concatenation)
+        ref_rgba, sf_prev, sf_post, prob_prev, prob_post = za.split_last(raw_ref, (4, 3, 3, 1, 1))
+        prob_prev, prob_post = prob_prev[..., 0], prob_post[..., 0]
         rgb_ref, depth_ref, rgb_fg, depth_fg, w_fg, w_dd, dd_sum = za.BlendFn.apply(
-            raw_ref[..., :4].contiguous(), raw_rgba.contiguous(), blend.contiguous(), z, dirs, noise(),
+            ref_rgba, raw_rgba.contiguous(), blend.contiguous(), z, dirs, noise(),
             float(raw_noise_std))
     else:
+        sf_prev, sf_post = raw_ref[..., 4:7], raw_ref[..., 7:10]
+        prob_prev, prob_post = raw_ref[..., 10], raw_ref[..., 11]
         rgb_ref, depth_ref, rgb_fg, depth_fg, w_fg, w_dd, dd_sum = zest_hip.composite_blend(
             raw_ref[..., :4], raw_rgba, blend, z, dirs, noise(), float(raw_noise_std))
     ret.update({'rgb_map_ref': rgb_ref[None], 'depth_map_ref': depth_ref[None],
@@ -294,9 +301,15 @@ def rendering(args, rays_pts, rays_ndc, depth_candidates, rays_dir,
     white_nb = bool(raw_noise_std)
     step = 1. / num_frames * 2.
 
-    def nb_render(raw):
-        rgb, _, _, w, _, _ = composite(raw[..., :4], None, 0.0, white_nb)
+    def nb_render(raw4):
+        rgb, _, _, w, _, _ = composite(raw4, None, 0.0, white_nb)
         return rgb, w
+
+    def parts(raw):             # (rgba, columns 4:7, columns 7:10) of a dynamic-net output
+        if train:
+            a, b, c, _ = za.split_last(raw, (4, 3, 3, 2))
+            return a, b, c
+        return raw[..., :4], raw[..., 4:7], raw[..., 7:10]
 
     def prob2d(w, p):
         if train:
@@ -304,21 +317,21 @@ def rendering(args, rays_pts, rays_ndc, depth_candidates, rays_dir,
         return zest_hip.weighted_complement_sum(w, p)
 
     ndc_prev = ndc + sf_prev
-    raw_prev = dyn_pass(ndc_prev, ref_frame_idx - step)
-    rgb_prev, w_prev = nb_render(raw_prev)
+    prev4, prev_4_7, prev_7_10 = parts(dyn_pass(ndc_prev, ref_frame_idx - step))
+    rgb_prev, w_prev = nb_render(prev4)
     ndc_post = ndc + sf_post
-    raw_post = dyn_pass(ndc_post, ref_frame_idx + step)
-    rgb_post, w_post = nb_render(raw_post)
-    ret.update({'raw_pts_prev': ndc_prev[None], 'raw_sf_prev2ref': raw_prev[None, ..., 7:10],
+    post4, post_4_7, post_7_10 = parts(dyn_pass(ndc_post, ref_frame_idx + step))
+    rgb_post, w_post = nb_render(post4)
+    ret.update({'raw_pts_prev': ndc_prev[None], 'raw_sf_prev2ref': prev_7_10[None],
                 'rgb_map_prev_dy': rgb_prev[None], 'raw_pts_post': ndc_post[None],
-                'raw_sf_post2ref': raw_post[None, ..., 4:7], 'rgb_map_post_dy': rgb_post[None],
+                'raw_sf_post2ref': post_4_7[None], 'rgb_map_post_dy': rgb_post[None],
                 'prob_map_prev': prob2d(w_prev, prob_prev)[None],
                 'prob_map_post': prob2d(w_post, prob_post)[None]})
     if chain_bwd:
-        ndc_pp, t_pp = ndc_prev + raw_prev[..., 4:7], ref_frame_idx - 2. / num_frames * 2.
+        ndc_pp, t_pp = ndc_prev + prev_4_7, ref_frame_idx - 2. / num_frames * 2.
     else:
-        ndc_pp, t_pp = ndc_post + raw_post[..., 7:10], ref_frame_idx + 2. / num_frames * 2.
+        ndc_pp, t_pp = ndc_post + post_7_10, ref_frame_idx + 2. / num_frames * 2.
     ret['raw_pts_pp'] = ndc_pp[None]
     if chain_5frames:
-        ret['rgb_map_pp_dy'] = nb_render(dyn_pass(ndc_pp, t_pp))[0][None]
+        ret['rgb_map_pp_dy'] = nb_render(dyn_pass(ndc_pp, t_pp)[..., :4])[0][None]
     return ret

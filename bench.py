@@ -9,9 +9,11 @@ synthetic rays through the fused HIP renderer, inputs resident in HBM.  Default 
 (BASELINE.json configs[1]): NSFF Balloon1 geometry, 1024 rays x 128 samples, static MLP,
 bf16 MFMA.  With N > 1 there is one rank per GPU - started by torch.distributed.run, or by this
 script itself when it is called from a plain shell (it spawns the ranks as child processes
-before touching the GPU) - every rank renders its own ray shard and the rendered pixels are
-all-gathered over RCCL inside the timed region (weak scaling: per-GPU work fixed; --scaling
-strong splits the workload's rays over the GPUs, e.g. configs[3]: 4096 x 192 over 8).
+before touching the GPU) - one scene is replicated on all of them (broadcast
+from rank 0 before the timed region), rank g renders the g-th contiguous block of one ray batch and the rendered
+pixels are all-gathered over RCCL inside the timed region (weak scaling: the batch is --gpus times the workload's
+rays, per-GPU work fixed; --scaling strong splits the workload's own rays over the GPUs, e.g. configs[3]:
+4096 x 192 over 8).
 At N = 1 the JSON also carries `modes`: the fp16 and the fp32-tolerance (split fp16) runs of the
 same kernel on the same workload.
 
@@ -51,6 +53,13 @@ WORKLOADS = {
                                    note="BASELINE configs[2], inference: static + dynamic nets"),
     "zest_val_4096x192": dict(R=4096, S=192, use_mvs=True, scene_flow=True,
                               note="BASELINE configs[3] shape on one GPU"),
+    # coherent rays: 1024 consecutive pixels (two image rows) of the 288 x 512 evaluation image, unjittered depths -
+    # the chunk the reference's whole-image loops render (networks.py:660-673); the ones above draw one random
+    # direction per ray, as a training batch does
+    "nsff_static_mvs_grid_1024x128": dict(R=1024, S=128, use_mvs=True, scene_flow=False, ray_mode="grid",
+                                          note="configs[1] + K=8 volume, rays of 1024 consecutive pixels"),
+    "nsff_zest_val_grid_1024x128": dict(R=1024, S=128, use_mvs=True, scene_flow=True, ray_mode="grid",
+                                        note="configs[2] inference, rays of 1024 consecutive pixels"),
     # parity-test cases (not bench lines): the other BASELINE configurations' geometry
     "llff_static_256x64": dict(R=256, S=64, use_mvs=False, scene_flow=False, H=640, W=960, V=3, focal=800.0,
                                note="BASELINE configs[0]: LLFF 640x960, static, use_mvs off"),
@@ -68,7 +77,8 @@ def build_workload(name, seed, device, rays=None, lively=True):
     R = rays or w["R"]
     V = w.get("V", 8)
     sc = zs.make_scene(seed, R, w["S"], H=w.get("H", 288), W=w.get("W", 512), V=V, V_dy=4, pad=24, vol_depth=128,
-                       focal=w.get("focal", 400.0), static_volume=w["use_mvs"], dynamic=w["scene_flow"])
+                       focal=w.get("focal", 400.0), static_volume=w["use_mvs"], dynamic=w["scene_flow"],
+                       ray_mode=w.get("ray_mode", "random"), grid_start=100 * w.get("W", 512))
     feat_dim = 8 + 4 * V
     sf = w["scene_flow"]
 
@@ -291,7 +301,16 @@ def main():
     else:
         import zest_hip
         zest_hip.lib()
-        d = build_workload(a.workload, 1234 + rank, dev, rays_per_gpu)
+        # The documented design: ONE scene - encoding volumes, source images, cameras and
+        # MLP weights replicated on every rank - and one batch of rays_per_gpu x world rays cut into contiguous
+        # blocks, rank g rendering block g (zest_parallel.shard_rays).  Every rank generates the batch from the same
+        # seed; the per-image tensors are then broadcast from rank 0 over RCCL, once, outside the timed region,
+        # as a whole-image loop would after building the volumes on one rank (zest_parallel.broadcast_scene).
+        d = build_workload(a.workload, 1234, dev, rays_per_gpu * world)
+        d.t = zest_parallel.shard_rays(d.t, dim=1)
+        d.t = {k: v.contiguous() for k, v in d.t.items()}
+        d.R = rays_per_gpu
+        zest_parallel.broadcast_scene([d.vol_s, d.imgs, d.vol_d, d.nb_imgs])
         set_mode(d, a.mode)
     force = os.environ.get("ZEST_FORCE_COLLECTIVE") == "1" and dist is not None     # 1-rank rehearsal
     # Multi-GPU: rank g renders its own ray blocks; the packed per-ray maps reach every
@@ -419,10 +438,11 @@ def main():
                         "kernel_ms": km, "roofline": {"bound": "mfma", "achieved": ach_m, "peak": MODES[m][2],
                                                       "unit": "TFLOP/s", "frac": ach_m / MODES[m][2],
                                                       "traffic": pmc_traffic(a.workload, m)}}
-        modes["f16x3"]["note"] = ("fp32 mode of the fused renderer: every product is 3 fp16 MFMAs (hi*hi + hi*lo + lo*hi); "
-                                  "achieved counts the ALGORITHMIC FLOPs once, so frac <= 1/3 by construction; "
-                                  "executed MFMA work = 3x; against the fp32 MFMA peak (157.3 TFLOP/s) the same "
-                                  "number is %.2fx" % (modes["f16x3"]["roofline"]["achieved"] / 157.3)) if "f16x3" in modes else None
+        if "f16x3" in modes:
+            modes["f16x3"]["note"] = ("fp32 mode of the fused renderer: every product is 3 fp16 MFMAs (hi*hi + hi*lo + lo*hi); "
+                                      "achieved counts the ALGORITHMIC FLOPs once, so frac <= 1/3 by construction; "
+                                      "executed MFMA work = 3x; against the fp32 MFMA peak (157.3 TFLOP/s) the same "
+                                      "number is %.2fx" % (modes["f16x3"]["roofline"]["achieved"] / 157.3))
         set_mode(d, a.mode)
         out["modes"] = modes
     if rank == 0:

@@ -16,6 +16,14 @@
  * argument the kernels do not cover is refused with a message, before any launch.
  * INTEGRATION.md shows the ctypes binding (zest-nerf_amd/zest_hip.py) a maintainer of
  * the reference would add.
+ *
+ * Devices.  Every entry point works on the CURRENT HIP device of the calling thread (hipSetDevice /
+ * torch.cuda.device): all pointers of a call, and the stream, must belong to it.  The library's own device-side
+ * state - the gather tables behind zest_mlp_pack, the job and position tables of the zest_mlp_train16_* path, the
+ * rocBLAS handle of the fp32 training path - is kept per device (keyed on the device that is current at the call),
+ * so one process may render and train on several devices, one current device per call.  A packed weight stream
+ * (zest_mlp_pack, zest_mlp_train16_pack) lives in the caller's buffer on the device it was packed on and is valid
+ * there only.
  */
 #ifndef ZEST_RENDER_H
 #define ZEST_RENDER_H
@@ -118,7 +126,8 @@ int zest_weighted_complement_sum(const float *w, const float *p, int R, int S, f
 int zest_embed_fwd(const float *x, int M, int C, int L, float *y, void *stream);
 
 /* One-off layout changes made when a volume / image set is first seen:
- * volume [8,D,H,W] -> channels-last [D,H,W,8] (one 32-byte read per trilinear corner);
+ * volume [8,D,H,W] -> channels-last, depth innermost [H,W,D,8] (one 32-byte read per trilinear corner; the corners of
+ * consecutive samples of a ray are contiguous runs);
  * imgs [V,3,H,W] -> [V,H,W,4] (rgb + pad, one 16-byte read per bilinear corner). */
 int zest_volume_to_cl(const float *vol, int D, int H, int W, float *vol_cl, void *stream);
 int zest_images_to_cl(const float *imgs, int V, int H, int W, float *imgs_cl, void *stream);
@@ -177,7 +186,7 @@ int zest_project_rays_bwd(const float *weights, const float *pts, const float *w
                           float *d_pts, void *stream);
 
 /* Trilinear lookup, zero padding, align_corners: index_point_feature
- * (reference utils.py:433-459).  vol_cl [D,H,W,8]; ndc [M,3] -> out [M,8]. */
+ * (reference utils.py:433-459).  vol_cl [H,W,D,8]; ndc [M,3] -> out [M,8]. */
 int zest_volume_lookup_fwd(const float *vol_cl, int D, int H, int W, const float *ndc, int M,
                            float *out, void *stream);
 
@@ -253,7 +262,7 @@ int zest_composite_blend_bwd(const float *raw_dy, const float *raw_st, const flo
 
 /* Gradient of zest_encode_fwd for the inputs that carry gradients in the reference's training
  * graph: g_x [R*S, C_in] -> g_ndc [R,S,3] (through the positional encoding and the trilinear
- * lookup) and, if g_vol_cl is given, += the channels-last volume gradient [D,Hv,Wv,8]
+ * lookup) and, if g_vol_cl is given, += the channels-last volume gradient [Hv,Wv,D,8]
  * (atomic scatter-add; zero it first).  vol_cl / V as in the forward call (NULL / 0: no
  * feature columns).  zest_volume_from_cl converts that gradient back to [8,D,H,W]. */
 int zest_encode_bwd(const float *g_x, const float *ndc, int R, int S, int has_time, float t,
@@ -328,7 +337,7 @@ int zest_mlp_fwd(const zest_mlp_desc *desc, int precision, const void *packed,
  * 5-7 rgb_map_ref, 8 depth_map_ref, 9-11 rgb_map_ref_dy, 12 depth_map_ref_dy,
  * 13 weights_map_dd; 14,15 reserved. */
 typedef struct zest_view_set {
-    const float *vol_cl;      /* [D,Hv,Wv,8] or NULL */
+    const float *vol_cl;      /* [Hv,Wv,D,8] or NULL */
     int32_t D, Hv, Wv;
     const float *imgs_cl;     /* [V,H,W,4] or NULL   */
     int32_t V, H, W;

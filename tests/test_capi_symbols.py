@@ -106,3 +106,24 @@ def test_fused_pass_shape_covers_every_block_once():
             assert rounds == max(-(-(b - a) // 8) for a, b in spans)
             dense_rounds = -(-(-(-n_blocks // 8)) // min(cus, -(-n_blocks // 8)))
             assert rounds <= dense_rounds or not ranges
+
+
+def test_train16_size_queries_refuse_other_mlp_shapes():
+    """The bf16 training kernels are unrolled for depth 8 / width 256 / skips [4]; the size queries of the C ABI
+    (no GPU call) answer 0 with an error text for any other descriptor, also AFTER a default-shape query has
+    been served (the table cache is keyed on the whole shape)."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "zest-nerf_amd"))
+    import zest_hip as zh
+    lib = zh.lib()
+    good = zh.MlpDesc(63, 40, 27, 1, 0, zh.HEAD_NONE)
+    assert lib.zest_mlp_train16_stash_bytes(C.byref(good), 4096) > 0
+    assert lib.zest_mlp_train16_work_bytes(C.byref(good), 4096) > 0
+    assert lib.zest_mlp_train16_packed_bytes(C.byref(good)) > 0
+    for bad in (zh.MlpDesc(63, 40, 27, 1, 0, zh.HEAD_NONE, 5, 128, 1 << 2),
+                zh.MlpDesc(63, 40, 27, 1, 0, zh.HEAD_NONE, 8, 256, 1 << 3),
+                zh.MlpDesc(63, 40, 27, 1, 2, zh.HEAD_NONE)):                      # 'v2': no bf16 training kernel
+        assert lib.zest_mlp_train16_stash_bytes(C.byref(bad), 4096) == 0
+        assert b"zest_mlp_train16" in lib.zest_last_error()
+        assert lib.zest_mlp_train16_work_bytes(C.byref(bad), 4096) == 0
+        assert lib.zest_mlp_train16_packed_bytes(C.byref(bad)) == 0

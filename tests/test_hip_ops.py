@@ -94,7 +94,12 @@ def test_volume_lookup(hip):
     import zest_hip
     inp, gold = gc.build("volume"), gc.load_golden("volume")
     vcl = zest_hip.volume_to_cl(G(inp["volume"]))
-    assert torch.equal(vcl, G(inp["volume"])[0].permute(1, 2, 3, 0).contiguous())
+    # the kernels' copy is channels-last and depth-innermost: [H,W,D,8]; and the way back ([8,D,H,W]) is exact
+    assert torch.equal(vcl, G(inp["volume"])[0].permute(2, 3, 1, 0).contiguous())
+    assert torch.equal(zest_hip.volume_from_cl(vcl), G(inp["volume"]))
+    odd = torch.randn(1, 8, 19, 7, 45, device="cuda:0")            # ragged against the 16 x 32 transpose tile
+    assert torch.equal(zest_hip.volume_to_cl(odd), odd[0].permute(2, 3, 1, 0).contiguous())
+    assert torch.equal(zest_hip.volume_from_cl(zest_hip.volume_to_cl(odd)), odd)
     close(zest_hip.volume_lookup(vcl, G(inp["ndc"])[0]), gold["feat"], name="volume")
 
 

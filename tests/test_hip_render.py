@@ -13,6 +13,7 @@ import pytest
 import torch
 
 import golden_cases as gc
+import oracle_run
 from test_hip_ops import G, close, ATOL, RTOL
 
 pytestmark = pytest.mark.gpu
@@ -39,12 +40,13 @@ def build_nets(sc, net_type="v0"):
 
 
 def render_scene(sc, c, precision=32, monkeypatch=None, maps_only=False, dtype16="bf16", net_type="v0",
-                 fp32_exact=False):
-    """renderer.rendering on a scene dict of golden_cases.render_inputs with the flags of case dict c."""
+                 fp32_exact=False, nets=None):
+    """renderer.rendering on a scene dict of golden_cases.render_inputs with the flags of case dict c.
+    nets: (static, dynamic) modules to reuse (their packed-weight caches with them)."""
     import zest_networks as networks
     import zest_renderer as renderer
     sf = sc["scene_flow"]
-    ns, nd = build_nets(sc, net_type)
+    ns, nd = nets if nets is not None else build_nets(sc, net_type)
     args = SimpleNamespace(netchunk=1024, feat_dim=sc["feat_dim"], feat_dim_dy=24, img_downscale=1.0,
                            use_color_volume=False, net_type=net_type, precision=precision,
                            zest_maps_only=maps_only, zest_dtype16=dtype16, zest_fp32_exact=fp32_exact)
@@ -105,6 +107,29 @@ def test_rendering_bf16_mode(hip, case, monkeypatch):
     for k in ("depth_map", "depth_map_ref"):
         if k in gold:
             close(ret[k][0], gold[k], atol=6e-2, rtol=0, name=k)
+
+
+@pytest.mark.parametrize("maps_only", [False, True], ids=["per-op", "fused"])
+def test_time_code_of_the_next_frame_is_not_served_from_the_cache(hip, maps_only):
+    """The reference's callers hand rendering() a NEW `time_codes[frame].to(device)` tensor per batch
+    (train.py:849, 1058); the allocator gives the next frame's code the block the last one just freed, at
+    version 0.  The packed weights carry the code in the biases of layers 0 and 5, so the cache must tell two
+    codes apart by value: frame A, then frame B in recycled memory, then A again - each against the oracle
+    evaluated with that frame's code."""
+    case = "render_static_timecodes"
+    sc, c = gc.build(case), gc.CASES[case]
+    nets = build_nets(sc, "v0")
+    code_a = np.array(sc["time_codes"], dtype=np.float32)
+    code_b = (code_a[..., ::-1] * 1.7 + 0.9).astype(np.float32).copy()
+    for code in (code_a, code_b, code_a, code_b):
+        sc_f = dict(sc, time_codes=code)
+        want = oracle_run.oracle_render(c, sc_f, explicit=False)
+        ret = render_scene(sc_f, c, 32, maps_only=maps_only, nets=nets)   # the code tensor dies with the call
+        for k in ("rgb_map", "depth_map"):
+            close(ret[k][0], want[k].numpy(), atol=ATOL, rtol=RTOL, name="%s/%s" % (case, k))
+    a = render_scene(dict(sc, time_codes=code_a), c, 32, maps_only=maps_only, nets=nets)["rgb_map"]
+    b = render_scene(dict(sc, time_codes=code_b), c, 32, maps_only=maps_only, nets=nets)["rgb_map"]
+    assert (a - b).abs().max() > 1e-3, "the two codes must render differently for this test to mean anything"
 
 
 FUSED_CASES = ["render_static_mvs", "render_static_nomvs", "render_static_white", "render_zest_val",

@@ -4,7 +4,7 @@
 // the training path, where per-sample tensors must exist in HBM.  The fused inference kernel
 // (fused.hip) uses the same device functions and never materialises these tensors.
 // All four are HBM/L2-bound gathers: one thread per sample, 16/32-byte corner reads from the
-// channels-last copies of the volume and the images.
+// channels-last copies of the volume ([H,W,D,8], depth innermost) and the images.
 #include "zest_sample_ops.cuh"
 
 namespace {
@@ -29,15 +29,30 @@ __global__ void embed_kernel(const float *__restrict__ x, int M, int C, int L,
     }
 }
 
-__global__ void volume_to_cl_kernel(const float *__restrict__ vol, long long nvox,
-                                    float4 *__restrict__ out) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nvox) return;
-    float c[8];
+// [8,D,H,W] -> [H,W,D,8] (zest_vox): a workgroup transposes the tile (one y, 32 x, 16 z) through LDS - 128-byte
+// runs along x in, one 512-byte run of 16 voxels per x out.
+constexpr int kTx = 32, kTz = 16, kTk = kTz * (kTx + 1) + 4;         // per-channel stride of the LDS tile
+
+__global__ __launch_bounds__(kThreads) void volume_to_cl_kernel(const float *__restrict__ vol, int D, int H, int W,
+                                                                float4 *__restrict__ out) {
+    __shared__ float tile[8 * kTk];
+    const int x0 = blockIdx.x * kTx, y = blockIdx.y, z0 = blockIdx.z * kTz;
+    const size_t plane = (size_t)H * W, nvox = plane * D;
+    const int tx = threadIdx.x & (kTx - 1), tr = threadIdx.x / kTx;
+    if (x0 + tx < W) {
 #pragma unroll
-    for (int k = 0; k < 8; k++) c[k] = vol[(size_t)k * nvox + i];   // coalesced per channel
-    out[2 * i] = make_float4(c[0], c[1], c[2], c[3]);
-    out[2 * i + 1] = make_float4(c[4], c[5], c[6], c[7]);
+        for (int k = 0; k < 8; k++)
+            for (int zz = tr; zz < kTz && z0 + zz < D; zz += kThreads / kTx)
+                tile[k * kTk + zz * (kTx + 1) + tx] = vol[k * nvox + (size_t)(z0 + zz) * plane + (size_t)y * W + x0 + tx];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kTx * kTz * 2; i += kThreads) {
+        const int xx = i / (2 * kTz), zz = (i % (2 * kTz)) >> 1, half = i & 1;
+        if (x0 + xx < W && z0 + zz < D) {
+            const float *t = tile + 4 * half * kTk + zz * (kTx + 1) + xx;
+            out[2 * zest_vox(z0 + zz, y, x0 + xx, D, W) + half] = make_float4(t[0], t[kTk], t[2 * kTk], t[3 * kTk]);
+        }
+    }
 }
 
 __global__ void images_to_cl_kernel(const float *__restrict__ imgs, int V, long long npix,
@@ -196,7 +211,7 @@ __global__ void encode_bwd_kernel(const float *__restrict__ g_x, const float *__
             const int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
             const int xi = x0 + dx, yi = y0 + dy, zi = z0 + dz;
             const bool ok = (unsigned)xi < (unsigned)Wv && (unsigned)yi < (unsigned)Hv && (unsigned)zi < (unsigned)D;
-            const size_t vox = ok ? ((size_t)zi * Hv + yi) * Wv + xi : 0;
+            const size_t vox = ok ? zest_vox(zi, yi, xi, D, Wv) : 0;
             const float wx = dx ? tx : 1.0f - tx, wy = dy ? ty : 1.0f - ty, wz = dz ? tz : 1.0f - tz;
             float dot = ok ? volf[8 * vox + ch] * gf : 0.0f;                    // octet-uniform `ok`
             dot += __shfl_xor(dot, 1, 64), dot += __shfl_xor(dot, 2, 64), dot += __shfl_xor(dot, 4, 64);
@@ -213,13 +228,28 @@ __global__ void encode_bwd_kernel(const float *__restrict__ g_x, const float *__
     }
 }
 
-// channels-last gradient volume [D,H,W,8] -> the reference's layout [8,D,H,W]
-__global__ void volume_from_cl_kernel(const float4 *__restrict__ cl, long long nvox, float *__restrict__ out) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nvox) return;
-    const float4 a = cl[2 * i], b = cl[2 * i + 1];
-    out[i] = a.x, out[nvox + i] = a.y, out[2 * nvox + i] = a.z, out[3 * nvox + i] = a.w;
-    out[4 * nvox + i] = b.x, out[5 * nvox + i] = b.y, out[6 * nvox + i] = b.z, out[7 * nvox + i] = b.w;
+// gradient volume [H,W,D,8] (zest_vox) -> the reference's layout [8,D,H,W]: the inverse tile transpose
+__global__ __launch_bounds__(kThreads) void volume_from_cl_kernel(const float4 *__restrict__ cl, int D, int H, int W,
+                                                                  float *__restrict__ out) {
+    __shared__ float tile[8 * kTk];
+    const int x0 = blockIdx.x * kTx, y = blockIdx.y, z0 = blockIdx.z * kTz;
+    const size_t plane = (size_t)H * W, nvox = plane * D;
+    for (int i = threadIdx.x; i < kTx * kTz * 2; i += kThreads) {
+        const int xx = i / (2 * kTz), zz = (i % (2 * kTz)) >> 1, half = i & 1;
+        if (x0 + xx < W && z0 + zz < D) {
+            const float4 v = cl[2 * zest_vox(z0 + zz, y, x0 + xx, D, W) + half];
+            float *t = tile + 4 * half * kTk + zz * (kTx + 1) + xx;
+            t[0] = v.x, t[kTk] = v.y, t[2 * kTk] = v.z, t[3 * kTk] = v.w;
+        }
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & (kTx - 1), tr = threadIdx.x / kTx;
+    if (x0 + tx < W) {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            for (int zz = tr; zz < kTz && z0 + zz < D; zz += kThreads / kTx)
+                out[k * nvox + (size_t)(z0 + zz) * plane + (size_t)y * W + x0 + tx] = tile[k * kTk + zz * (kTx + 1) + tx];
+    }
 }
 
 inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
@@ -245,9 +275,9 @@ extern "C" int zest_encode_bwd(const float *g_x, const float *ndc, int R, int S,
 extern "C" int zest_volume_from_cl(const float *vol_cl, int D, int H, int W, float *vol, void *stream) {
     ZEST_CHECK_ARG(vol_cl && vol && aligned16(vol_cl), "zest_volume_from_cl: bad pointer");
     ZEST_CHECK_ARG(D >= 1 && H >= 1 && W >= 1, "zest_volume_from_cl: bad shape");
-    const long long n = (long long)D * H * W;
-    hipLaunchKernelGGL(volume_from_cl_kernel, dim3(zest_div_up(n, kThreads)), dim3(kThreads), 0,
-                       (hipStream_t)stream, (const float4 *)vol_cl, n, vol);
+    ZEST_CHECK_ARG(H <= 65535 && D <= 65535 * kTz, "zest_volume_from_cl: volume too large for the launch grid");
+    hipLaunchKernelGGL(volume_from_cl_kernel, dim3(zest_div_up(W, kTx), H, zest_div_up(D, kTz)), dim3(kThreads), 0,
+                       (hipStream_t)stream, (const float4 *)vol_cl, D, H, W, vol);
     ZEST_RETURN_LAUNCH("zest_volume_from_cl");
 }
 
@@ -267,9 +297,9 @@ extern "C" int zest_volume_to_cl(const float *vol, int D, int H, int W, float *v
                                  void *stream) {
     ZEST_CHECK_ARG(vol && vol_cl && aligned16(vol_cl), "zest_volume_to_cl: bad pointer");
     ZEST_CHECK_ARG(D >= 1 && H >= 1 && W >= 1, "zest_volume_to_cl: bad shape");
-    const long long n = (long long)D * H * W;
-    hipLaunchKernelGGL(volume_to_cl_kernel, dim3(zest_div_up(n, kThreads)), dim3(kThreads), 0,
-                       (hipStream_t)stream, vol, n, (float4 *)vol_cl);
+    ZEST_CHECK_ARG(H <= 65535 && D <= 65535 * kTz, "zest_volume_to_cl: volume too large for the launch grid");
+    hipLaunchKernelGGL(volume_to_cl_kernel, dim3(zest_div_up(W, kTx), H, zest_div_up(D, kTz)), dim3(kThreads), 0,
+                       (hipStream_t)stream, vol, D, H, W, (float4 *)vol_cl);
     ZEST_RETURN_LAUNCH("zest_volume_to_cl");
 }
 

@@ -30,7 +30,7 @@ constexpr int kCamStride = 24;            // floats per camera in LDS: 12 (R|T r
 struct FusedNet {                         // one MLP + its feature sources
     const float *bias;                    // packed: bias area
     const uint4 *tiles;                   // packed: tile stream
-    const float4 *vol;                    // [D,Hv,Wv,8] or null
+    const float4 *vol;                    // [Hv,Wv,D,8] (zest_vox) or null
     const float4 *imgs;                   // [V,H,W,4] or null
     const float *w2cs, *intr;             // cameras or null
     int D, Hv, Wv, V, H, W;
@@ -204,7 +204,7 @@ __device__ __forceinline__ void encode_feat_operand(const FusedNet &n, const flo
                 const int xc = min(max(xi, 0), n.Wv - 1), yc = min(max(yi, 0), n.Hv - 1),
                           zc = min(max(zi, 0), n.D - 1);
                 wgt[c] = ok ? (dx ? tx : 1.0f - tx) * (dy ? ty : 1.0f - ty) * (dz ? tz : 1.0f - tz) : 0.0f;
-                tap[c] = n.vol[2 * (((size_t)zc * n.Hv + yc) * n.Wv + xc) + grp];
+                tap[c] = n.vol[2 * ((yc * n.Wv + xc) * n.D + zc) + grp];      // zest_vox, 32-bit (checked by the host)
             }
 #pragma unroll
             for (int c = 0; c < 8; c++) {

@@ -44,6 +44,8 @@ bool fill_net(const zest_mlp_desc *d, const void *packed, const zest_view_set *v
             return *err = "a net with features needs volume, images and cameras", false;
         if (vs->D < 1 || vs->Hv < 1 || vs->Wv < 1 || vs->H < 2 || vs->W < 2)
             return *err = "bad volume / image shape", false;
+        if ((long long)vs->D * vs->Hv * vs->Wv >= (1LL << 30))
+            return *err = "volume too large for the fused kernel's 32-bit voxel indices (2^30 voxels)", false;
         if (vs->V < 1 || vs->V > zest::kMaxViews || 8 + 4 * vs->V != d->in_ch_feat)
             return *err = "view count does not match in_ch_feat = 8 + 4V", false;
         if (((uintptr_t)vs->vol_cl | (uintptr_t)vs->imgs_cl) & 15)

@@ -24,15 +24,19 @@ struct DevPlan {
 };
 
 std::mutex g_mu;
-std::map<std::tuple<int, int, int, int, int, int, int, int, int, int, int>, DevPlan *> g_plans;
+std::map<std::tuple<int, int, int, int, int, int, int, int, int, int, int, int>, DevPlan *> g_plans;   // per shape AND device
 
 constexpr int kOrderBwd = 99;       // key of the training path's backward-data stream (bf16, build_bwd_plan)
 
-// Plans are built once per (shape, precision, order) and kept for the life of the process.
+// Plans are built once per (shape, precision, order, device) and kept for the life of the process: a plan's gather
+// tables live in the memory of the device that was current when they were uploaded, so the current device is
+// part of the key (include/zest_render.h, "Devices").
 DevPlan *get_plan(const zest_mlp_desc &d, int precision, int order, bool need_tables) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     std::lock_guard<std::mutex> lk(g_mu);
     auto key = std::make_tuple(d.in_ch_pts, d.use_feat ? d.in_ch_feat : 0, d.in_ch_views,
-                               d.use_feat, d.net_type, d.head, precision, order, d.depth, d.width, d.skip_mask);
+                               d.use_feat, d.net_type, d.head, precision, order, d.depth, d.width, d.skip_mask, dev);
     auto it = g_plans.find(key);
     DevPlan *dp = it == g_plans.end() ? nullptr : it->second;
     if (!dp) {

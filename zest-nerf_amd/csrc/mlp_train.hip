@@ -11,6 +11,7 @@
 // Replaces the autograd of Renderer.forward / Renderer_linear.forward
 // (reference networks.py:150-221, 283-319).
 #include <rocblas/rocblas.h>
+#include <map>
 #include <mutex>
 #include "mlp_plan.h"
 #include "zest_common.cuh"
@@ -48,15 +49,21 @@ bool shape_of(const zest_mlp_desc &d, Shape *out) {
     return true;
 }
 
-rocblas_handle g_handle = nullptr;
+std::map<int, rocblas_handle> g_handles;        // one per device: a handle belongs to the device it was created on
 std::mutex g_mu;
 
 rocblas_handle handle_for(hipStream_t st) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_handle && rocblas_create_handle(&g_handle) != rocblas_status_success) return nullptr;
-    rocblas_set_stream(g_handle, st);
-    rocblas_set_pointer_mode(g_handle, rocblas_pointer_mode_host);
-    return g_handle;
+    rocblas_handle &h = g_handles[dev];
+    if (!h && rocblas_create_handle(&h) != rocblas_status_success) {
+        h = nullptr;
+        return nullptr;
+    }
+    rocblas_set_stream(h, st);
+    rocblas_set_pointer_mode(h, rocblas_pointer_mode_host);
+    return h;
 }
 
 // Row-major helpers on top of column-major sgemm.

@@ -45,7 +45,7 @@ struct Sizes {
     long long blocks;
     size_t tile_bytes, mask_bytes, grad_bytes, side_bytes;
 };
-constexpr size_t kPtrTableBytes = 256;          // 2 * ZEST_P_COUNT gradient pointers, padded
+constexpr size_t kPtrTableBytes = 256;          // reserved (rounds 1-2 kept a device copy of the gradient pointers here)
 Sizes sizes_of(int M) {
     Sizes s;
     s.blocks = train_blocks(M);
@@ -610,9 +610,12 @@ __global__ __launch_bounds__(kWaves * 64, kWaves / 4) void train16_dw_kernel(
 // added to the fp32 gradients through the job's position maps.  Every gradient element belongs to exactly one
 // accumulator element of one job (the two jobs of the skip layer and of the view layer own different columns), so
 // plain read-modify-write is enough - and the result does not depend on the order workgroups finish in.
+struct GradPtrs {                    // the caller's gradient tensors, passed BY VALUE as a kernel argument (208 bytes)
+    float *p[2 * ZEST_P_COUNT];
+};
 __global__ __launch_bounds__(256) void train16_dw_reduce_kernel(const DwJob *__restrict__ jobs, int n_jobs,
-                                                                const float4 *__restrict__ partial,
-                                                                float *const *__restrict__ g_params) {
+                                                                const float4 *__restrict__ partial, const GradPtrs g) {
+    float *const *g_params = g.p;
     const int per_job = kWaves * kDwSlots * 64;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_jobs * per_job) return;
@@ -648,14 +651,24 @@ struct TrainTables {                 // per MLP shape, device resident
     MlpPlan fwd;                     // forward plan (stream size check, operand tile counts)
 };
 std::mutex g_mu;
-std::map<std::tuple<int, int, int, int, int, int>, TrainTables *> g_tables;
+std::map<std::tuple<int, int, int, int, int, int, int, int, int, int>, TrainTables *> g_tables;    // per shape AND device
 
 TrainTables *tables_for(const zest_mlp_desc &d) {
+    // the kernels are unrolled for the shipped shape (8 x 256, skip after layer 4): refused here for every entry
+    // point, whatever an earlier call has cached
+    const char *err = nullptr;
+    zest::MlpShape sh;
+    if (!zest::mlp_shape(d, &sh, &err) || !sh.is_default) {
+        zest_set_error("zest_mlp_train16: %s", err ? err : "the bf16 training kernels cover depth 8 / width 256 / skips [4] only");
+        return nullptr;
+    }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     std::lock_guard<std::mutex> lk(g_mu);
-    auto key = std::make_tuple(d.in_ch_pts, d.use_feat ? d.in_ch_feat : 0, d.in_ch_views, d.use_feat, d.net_type, d.head);
+    auto key = std::make_tuple(d.in_ch_pts, d.use_feat ? d.in_ch_feat : 0, d.in_ch_views, d.use_feat, d.net_type, d.head,
+                               d.depth, d.width, d.skip_mask, dev);      // the tables live in the memory of `dev`
     auto it = g_tables.find(key);
     if (it != g_tables.end()) return it->second;
-    const char *err = nullptr;
     TrainTables *t = new TrainTables();
     std::vector<DwJob> jobs;
     if (d.net_type != 0 || !build_plan(d, ZEST_PREC_BF16, ORDER_ACC, &t->fwd, &err, true) ||
@@ -669,10 +682,8 @@ TrainTables *tables_for(const zest_mlp_desc &d) {
         // workgroup, hardly by the tiles it streams per block (an iteration costs about the same whether it stages
         // 5 tiles or 16), so a split in proportion to the tiles leaves the light jobs (rgb: 5 tiles, 7 workgroups)
         // running 1.6x longer than the even one (measured: 990 us against 600).
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-            cus = 256;
+        int cus = 256;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
         const int nj = t->n_jobs;
         if (cus < nj) cus = nj;
         std::vector<int> wgs(nj);
@@ -713,20 +724,31 @@ size_t dw_partial_bytes() {
 
 }  // namespace
 
+// 0 + error text for a shape the bf16 training kernels do not cover
+static bool train16_shape_ok(const zest_mlp_desc *desc) {
+    const char *err = nullptr;
+    zest::MlpShape sh;
+    if (desc && zest::mlp_shape(*desc, &sh, &err) && sh.is_default && desc->net_type == 0) return true;
+    zest_set_error("zest_mlp_train16: %s", !desc ? "null descriptor" : err ? err :
+                   "the bf16 training kernels cover 'v0' nets of depth 8 / width 256 / skips [4] only");
+    return false;
+}
+
 extern "C" size_t zest_mlp_train16_stash_bytes(const zest_mlp_desc *desc, int M) {
-    if (!desc || M <= 0) return 0;
+    if (!train16_shape_ok(desc) || M <= 0) return 0;
     const Sizes s = sizes_of(M);
     return s.tile_bytes + s.mask_bytes;
 }
 extern "C" size_t zest_mlp_train16_work_bytes(const zest_mlp_desc *desc, int M) {
-    if (!desc || M <= 0) return 0;
+    if (!train16_shape_ok(desc) || M <= 0) return 0;
     const Sizes s = sizes_of(M);
     return s.grad_bytes + s.side_bytes + kPtrTableBytes + dw_partial_bytes();
 }
-extern "C" size_t zest_mlp_train16_packed_bytes(const zest_mlp_desc *desc) { return desc ? zest::bwd_stream_bytes(*desc) : 0; }
+extern "C" size_t zest_mlp_train16_packed_bytes(const zest_mlp_desc *desc) { return train16_shape_ok(desc) ? zest::bwd_stream_bytes(*desc) : 0; }
 
 extern "C" int zest_mlp_train16_pack(const zest_mlp_desc *desc, const float *const *params, void *packed, void *stream) {
     ZEST_CHECK_ARG(desc && params && packed && ((uintptr_t)packed & 15) == 0, "zest_mlp_train16_pack: bad argument");
+    if (!train16_shape_ok(desc)) return (int)hipErrorInvalidValue;
     return zest::pack_bwd_stream(*desc, params, packed, (hipStream_t)stream);
 }
 
@@ -761,7 +783,6 @@ extern "C" int zest_mlp_train16_bwd(const zest_mlp_desc *desc, const void *packe
     const uint2 *masks = (const uint2 *)((const char *)stash + s.tile_bytes);
     uint4 *grad = (uint4 *)work;
     float4 *pts_side = (float4 *)((char *)work + s.grad_bytes);
-    float **g_dev = (float **)((char *)work + s.grad_bytes + s.side_bytes);
     const int cus = cu_count();
     if (stages & 1) {
         const int units = zest::bwd_stream_units_of(d);
@@ -808,18 +829,17 @@ extern "C" int zest_mlp_train16_bwd(const zest_mlp_desc *desc, const void *packe
 #undef ZEST_FIN
     }
     if (stages & 4) {
-        hipError_t e = hipMemcpyAsync(g_dev, g_params, 2 * ZEST_P_COUNT * sizeof(float *), hipMemcpyHostToDevice, st);
-        if (e != hipSuccess) {
-            zest_set_error("zest_mlp_train16_bwd: uploading the gradient pointers: %s", hipGetErrorString(e));
-            return (int)e;
-        }
+        // the gradient pointers travel in the kernel's argument block (an upload from the caller's pageable
+        // table was a staging copy per backward call)
+        GradPtrs gp;
+        for (int i = 0; i < 2 * ZEST_P_COUNT; i++) gp.p[i] = g_params[i];
         // one resident workgroup per CU (128 accumulator registers per lane): more workgroups would only run in a
         // second round and add their 272 KB of partial sums each
         float4 *partial = (float4 *)((char *)work + s.grad_bytes + s.side_bytes + kPtrTableBytes);
         hipLaunchKernelGGL(train16_dw_kernel, dim3(t->n_wg), dim3(kWaves * 64), 0, st, t->jobs, t->n_jobs,
                            stash_tiles, (const uint4 *)grad, M, partial);
         hipLaunchKernelGGL(train16_dw_reduce_kernel, dim3(zest_div_up(t->n_jobs * kWaves * kDwSlots * 64, 256)), dim3(256), 0, st,
-                           t->jobs, t->n_jobs, (const float4 *)partial, (float *const *)g_dev);
+                           t->jobs, t->n_jobs, (const float4 *)partial, gp);
     }
     ZEST_RETURN_LAUNCH("zest_mlp_train16_bwd");
 }

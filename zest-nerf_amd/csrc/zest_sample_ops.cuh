@@ -17,7 +17,18 @@ __device__ __forceinline__ float zest_unnorm(float c01, int size) {
     return (g + 1.0f) * 0.5f * (float)(size - 1);
 }
 
-// Trilinear, zero padding.  vol: channels-last [D,H,W,8] as float4 pairs.  CH4 selects which
+// Voxel (z, y, x) of the kernels' copy of the encoding volume: channels-last and DEPTH-INNERMOST, [H][W][D][8].
+// Consecutive samples of a ray advance about one depth plane each at slowly varying (x, y) (the volume is the
+// reference view's frustum), so the taps that the 16 lanes of a lane group issue for one corner are one
+// contiguous run of 32-byte voxels: 4-5 lines of 128 B instead of 16 lines 675 KB apart in a [D][H][W][8] copy.
+__device__ __forceinline__ size_t zest_vox(int zi, int yi, int xi, int D, int W) {
+    return ((size_t)yi * W + xi) * D + zi;
+}
+#ifdef ZEST_VOX_PLANES
+#error "the plane-major [D][H][W][8] copy of rounds 1-2 is gone; profiles/r03_ab_volume_layout.txt holds the A/B"
+#endif
+
+// Trilinear, zero padding.  vol: [H,W,D,8] (zest_vox) as float4 pairs.  CH4 selects which
 // half of the 8 channels (0: ch0-3, 1: ch4-7, 2: all eight -> out[0..7]).
 template <int CH4>
 __device__ __forceinline__ void zest_volume_trilerp(const float4 *__restrict__ vol, int D, int H,
@@ -50,7 +61,7 @@ __device__ __forceinline__ void zest_volume_trilerp(const float4 *__restrict__ v
                 const bool ok = (unsigned)xi < (unsigned)W && (unsigned)yi < (unsigned)H &&
                                 (unsigned)zi < (unsigned)D;
                 if (ok) {
-                    const size_t vox = ((size_t)zi * H + yi) * W + xi;
+                    const size_t vox = zest_vox(zi, yi, xi, D, W);
                     if (CH4 != 1) {
                         const float4 a = vol[2 * vox];
                         out[0] = fmaf(w, a.x, out[0]), out[1] = fmaf(w, a.y, out[1]);

@@ -239,7 +239,7 @@ def embed(x, n_freqs):
 
 
 def volume_to_cl(vol):
-    """[1,8,D,H,W] or [8,D,H,W] -> channels-last [D,H,W,8]."""
+    """[1,8,D,H,W] or [8,D,H,W] -> the kernels' copy: channels-last, depth innermost [H,W,D,8]."""
     vol = _dev(vol, "volume")
     if vol.dim() == 5:
         if vol.shape[0] != 1:
@@ -248,7 +248,7 @@ def volume_to_cl(vol):
     if vol.shape[0] != 8:
         raise RuntimeError("zest_hip: encoding volume must have 8 channels, got %d" % vol.shape[0])
     _, D, H, W = vol.shape
-    out = torch.empty(D, H, W, 8, device=vol.device, dtype=torch.float32)
+    out = torch.empty(H, W, D, 8, device=vol.device, dtype=torch.float32)
     _check(lib().zest_volume_to_cl(_ptr(vol), D, H, W, _ptr(out), _stream(vol)), "zest_volume_to_cl")
     return out
 
@@ -389,7 +389,7 @@ def images_to_cl(imgs):
 def volume_lookup(vol_cl, ndc):
     ndc = _dev(ndc, "ndc", (None,) * (ndc.dim() - 1) + (3,))
     vol_cl = _dev(vol_cl, "vol_cl", (None, None, None, 8))
-    D, H, W, _ = vol_cl.shape
+    H, W, D, _ = vol_cl.shape
     M = ndc.numel() // 3
     out = torch.empty(*ndc.shape[:-1], 8, device=ndc.device, dtype=torch.float32)
     _check(lib().zest_volume_lookup_fwd(_ptr(vol_cl), D, H, W, _ptr(ndc), M, _ptr(out), _stream(ndc)),
@@ -422,7 +422,7 @@ def encode(ndc, pts, rays_dir, t=None, vol_cl=None, imgs_cl=None, w2cs=None, int
     D = Hv = Wv = V = H = W = 0
     if vol_cl is not None:
         vol_cl, imgs_cl = _dev(vol_cl, "vol_cl", (None, None, None, 8)), _dev(imgs_cl, "imgs_cl", (None, None, None, 4))
-        D, Hv, Wv, _ = vol_cl.shape
+        Hv, Wv, D, _ = vol_cl.shape
         V, H, W, _ = imgs_cl.shape
         if pts is None or w2cs is None or intrinsics is None or w2cs.numel() < 16 * V or intrinsics.numel() < 9 * V:
             raise RuntimeError("zest_hip: encode with features needs pts and one pose (4x4) and intrinsic (3x3) per source view")
@@ -514,7 +514,7 @@ def composite_blend_bwd(raw_dy, raw_st, blend, z, rays_dir, noise, noise_std, g_
 
 # ------------------------------------------------------------------- training path (backward)
 def encode_bwd(g_x, ndc, t, vol_cl, V, want_vol_grad):
-    """-> g_ndc [R,S,3], g_vol_cl [D,H,W,8] or None."""
+    """-> g_ndc [R,S,3], g_vol_cl [H,W,D,8] or None."""
     ndc = _dev(ndc, "ndc", (None, None, 3))
     R, S, _ = ndc.shape
     c_in = (4 if t is not None else 3) * 21 + (8 + 4 * int(V) if vol_cl is not None else 0) + 27
@@ -523,7 +523,7 @@ def encode_bwd(g_x, ndc, t, vol_cl, V, want_vol_grad):
     g_vol = None
     if vol_cl is not None:
         vol_cl = _dev(vol_cl, "vol_cl", (None, None, None, 8))
-        D, Hv, Wv, _ = vol_cl.shape
+        Hv, Wv, D, _ = vol_cl.shape
         if want_vol_grad:
             g_vol = torch.zeros_like(vol_cl)
     g_ndc = torch.empty_like(ndc)
@@ -535,7 +535,7 @@ def encode_bwd(g_x, ndc, t, vol_cl, V, want_vol_grad):
 
 def volume_from_cl(vol_cl):
     vol_cl = _dev(vol_cl, "vol_cl", (None, None, None, 8))
-    D, H, W, _ = vol_cl.shape
+    H, W, D, _ = vol_cl.shape
     out = torch.empty(1, 8, D, H, W, device=vol_cl.device, dtype=torch.float32)
     _check(lib().zest_volume_from_cl(_ptr(vol_cl), D, H, W, _ptr(out), _stream(vol_cl)), "zest_volume_from_cl")
     return out
@@ -742,7 +742,7 @@ def make_view_set(vol_cl=None, imgs_cl=None, w2cs=None, intrinsics=None):
     vs = ViewSet()
     keep = []
     if vol_cl is not None:
-        vs.vol_cl, (vs.D, vs.Hv, vs.Wv) = _ptr(vol_cl), vol_cl.shape[:3]
+        vs.vol_cl, (vs.Hv, vs.Wv, vs.D) = _ptr(vol_cl), vol_cl.shape[:3]
         vs.imgs_cl, (vs.V, vs.H, vs.W) = _ptr(imgs_cl), imgs_cl.shape[:3]
         keep += [vol_cl, imgs_cl]
     if w2cs is not None:

@@ -16,6 +16,8 @@ ZEST_PRECISION = fp32 | f16x3 | bf16 | f16 overrides both.
 """
 import os
 
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -174,16 +176,31 @@ class _MlpBase(nn.Module):
         if params is None:
             params = self.__dict__["_zest_params"] = tuple(self.named_parameters())
         stamp = tuple((p.data_ptr(), p._version) for _, p in params)
-        if time_codes is not None:
-            stamp += ((time_codes.data_ptr(), time_codes._version),)
         key = precision if desc is None else (precision, desc.use_feat, desc.net_type, desc.head)
         hit = self._packed.get(key)
-        if hit is None or hit[0] != stamp:
+        fresh = hit is not None and hit[0] == stamp
+        if fresh and time_codes is not None:
+            # The frame's code is folded into the packed biases, so it is part of what the entry is valid for.
+            # Its address and version counter do not identify it: the reference's callers build
+            # `self.time_codes[keyframe_id].to(device)` anew for every batch (train.py:849, 1058) and the caching
+            # allocator hands the block just freed to the next frame's code at version 0.  Same live tensor object
+            # at the same version = unchanged; any other tensor is compared by value with the copy the entry
+            # keeps (T floats: one small device compare per call for such callers).
+            ref, ver, copy = hit[2]
+            if not (ref() is time_codes and ver == time_codes._version):
+                fresh = (copy.shape == time_codes.shape and copy.device == time_codes.device
+                         and bool(torch.equal(copy, time_codes.detach())))
+                if fresh:
+                    hit = (hit[0], hit[1], (weakref.ref(time_codes), time_codes._version, copy))
+                    self._packed[key] = hit
+        if not fresh:
             desc = self._desc() if desc is None else desc
             with torch.no_grad():
                 eff = self.effective_parameters(time_codes)
             state = {"nerf." + k: v.detach() for k, v in eff.items()}
-            hit = (stamp, zest_hip.mlp_pack(desc, precision, zest_hip.param_table(state, desc)))
+            tc = None if time_codes is None else (weakref.ref(time_codes), time_codes._version,
+                                                  time_codes.detach().clone())
+            hit = (stamp, zest_hip.mlp_pack(desc, precision, zest_hip.param_table(state, desc)), tc)
             self._packed[key] = hit
         return hit[1]
 
@@ -648,7 +665,7 @@ class DyMVSNeRF_G(_Generator):
                     chunk_idx += n
             finally:
                 a.zest_maps_only = maps_only
-            if world > 1:
+            if zest_parallel.collectives_active():
                 widths = [3, 1, 3, 1, 3, 1, 1]
                 cols = [torch.cat(outs[k]).reshape(-1, w) if outs[k] else sc['imgs'].new_zeros(0, w)
                         for k, w in zip(self.VAL_KEYS, widths)]

@@ -11,17 +11,30 @@ instead of one per map.
 Works with any torch.distributed backend: "nccl" (= RCCL on ROCm) on GPUs, "gloo" in the CPU
 tests, where the per-shard render function is the oracle.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 __all__ = ["shard_bounds", "shard_rays", "gather_maps", "render_sharded", "broadcast_scene",
-           "allreduce_grads"]
+           "allreduce_grads", "collectives_active"]
+
+# Rehearsal switch: run the collectives even in a ONE-rank group, so the RCCL legs of this module (and of
+# DyMVSNeRF_G.forward_val, bench.py) execute on a single-GPU box: tests/test_hip_rccl.py sets it,
+# ZEST_FORCE_COLLECTIVE=1 does the same from the environment.  With more than one rank it changes nothing.
+FORCE_SINGLE_RANK = os.environ.get("ZEST_FORCE_COLLECTIVE") == "1"
 
 
 def _world(group=None):
     if not (dist.is_available() and dist.is_initialized()):
         return 1, 0
     return dist.get_world_size(group), dist.get_rank(group)
+
+
+def collectives_active(group=None, force=False):
+    """True when the exchange steps run: more than one rank, or a one-rank group under the rehearsal switch."""
+    world, _ = _world(group)
+    return world > 1 or ((force or FORCE_SINGLE_RANK) and dist.is_available() and dist.is_initialized())
 
 
 def shard_bounds(n_rays, world, rank):
@@ -51,7 +64,7 @@ def gather_maps(local_maps, n_rays, group=None, async_op=False, force=False, per
     reading the tensor, so the gather of one batch overlaps the rendering of the next.
     `force` runs the collective even in a 1-rank group (rehearsal of the code path)."""
     world, rank = _world(group)
-    if world == 1 and not (force and dist.is_available() and dist.is_initialized()):
+    if not collectives_active(group, force):
         return (local_maps, None) if async_op else local_maps
     if per is None:
         _, _, per = shard_bounds(n_rays, world, rank)
@@ -65,13 +78,13 @@ def gather_maps(local_maps, n_rays, group=None, async_op=False, force=False, per
     return (out[:n_rays], work) if async_op else out[:n_rays]
 
 
-def allreduce_grads(params, group=None, bucket_bytes=32 << 20):
+def allreduce_grads(params, group=None, bucket_bytes=32 << 20, force=False):
     """Average the .grad of `params` over the ranks (data-parallel training of the MLPs:
     ~4.9 MB of fp32 gradients per net).  Gradients are packed into buckets of bucket_bytes so
     the ring all-reduce over xGMI moves a few large messages instead of 60 small ones."""
     world, _ = _world(group)
     grads = [p.grad for p in params if p.grad is not None]
-    if world == 1 or not grads:
+    if not collectives_active(group, force) or not grads:
         return
     bucket, size = [], 0
 
@@ -103,11 +116,10 @@ def render_sharded(render_fn, rays, n_rays, group=None):
     return gather_maps(local, n_rays, group)
 
 
-def broadcast_scene(tensors, src=0, group=None):
+def broadcast_scene(tensors, src=0, group=None, force=False):
     """Replicate per-image tensors (encoding volumes, source images, cameras) built on one rank:
     86.5 MB per NSFF volume, once per image, amortised over ~144 ray chunks."""
-    world, _ = _world(group)
-    if world > 1:
+    if collectives_active(group, force):
         for t in tensors:
             if t is not None:
                 dist.broadcast(t, src=src, group=group)

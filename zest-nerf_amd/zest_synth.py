@@ -121,21 +121,32 @@ def project_ndc(pts, w2c, K, W, H, near, far, pad):
 # ------------------------------------------------------------------------- scene
 def make_scene(seed, R, S, H=288, W=512, V=8, V_dy=4, pad=24, vol_depth=128,
                vol_hw=None, focal=400.0, near=2.0, far=6.0, static_volume=True,
-               dynamic=False, stratified=True, ndc_mode="project"):
+               dynamic=False, stratified=True, ndc_mode="project", ray_mode="random", grid_start=0):
     """All tensors one ``rendering`` call consumes, as float32 numpy arrays.
 
     Returns a dict with rays_pts [1,R,S,3], rays_ndc [1,R,S,3],
     depth_candidates [1,R,S], rays_dir [1,R,3], and (optionally) vol_static
     [1,8,D,h,w], imgs [1,V,3,H,W], w2cs/intrinsics [1,V+1,...]; with ``dynamic``
     also vol_dynamic, nb_imgs [1,V_dy,3,H,W] and nb_w2cs/nb_intrinsics.
+
+    ray_mode "random": one random direction per ray (the batch a training step draws); "grid": the rays of
+    R consecutive pixels of the H x W target image in row-major order starting at pixel ``grid_start`` - the
+    chunk a whole-image evaluation loop renders (/root/reference/networks.py:660-673), with its depth samples
+    unjittered as there (``stratified`` is ignored).
     """
     g = rng(seed)
     sc = {"R": R, "S": S, "H": H, "W": W, "V": V, "V_dy": V_dy, "pad": pad}
     if vol_hw is None:
         vol_hw = (H // 4 + 2 * pad, W // 4 + 2 * pad)
     d = np.empty((1, R, 3), np.float32)
-    d[..., 0] = g.uniform(-0.5, 0.5, size=(1, R))
-    d[..., 1] = g.uniform(-0.5, 0.5, size=(1, R))
+    if ray_mode == "grid":
+        pix = (grid_start + np.arange(R)) % (H * W)
+        d[0, :, 0] = ((pix % W) + 0.5 - W / 2.0) / focal
+        d[0, :, 1] = ((pix // W) + 0.5 - H / 2.0) / focal
+        stratified = False
+    else:
+        d[..., 0] = g.uniform(-0.5, 0.5, size=(1, R))
+        d[..., 1] = g.uniform(-0.5, 0.5, size=(1, R))
     d[..., 2] = 1.0
     z = np.linspace(near, far, S, dtype=np.float32)[None, None, :].repeat(R, 1)
     if stratified and S > 1:

@@ -2,7 +2,7 @@
 
 `index_point_feature` and `build_color_volume` keep the reference's signatures
 (/root/reference/utils.py:433-505) and run the gather kernels behind the C ABI.  The
-channels-last copies the kernels read (volume [D,H,W,8], images [V,H,W,4]) are made once per
+channels-last copies the kernels read (volume [H,W,D,8] - depth innermost -, images [V,H,W,4]) are made once per
 tensor and cached by storage identity + version: the reference builds a volume once per
 image and renders ~144 ray chunks from it (networks.py:660).
 """
@@ -42,7 +42,7 @@ def _cached(kind, t, make):
 
 
 def volume_channels_last(volume_feature):
-    """[1,8,D,H,W] -> cached channels-last [D,H,W,8] device tensor."""
+    """[1,8,D,H,W] -> cached channels-last, depth-innermost [H,W,D,8] device tensor."""
     return _cached("vol", volume_feature, zest_hip.volume_to_cl)
 
 

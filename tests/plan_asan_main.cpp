@@ -17,6 +17,23 @@ int main() {
                                 const int precision = prec;      // ZEST_PREC_F32, _BF16, _F16, _F16X3
                                 if (!zest::build_plan(d, precision, order, &p, &err, true)) continue;
                                 n++;
+                                // the feature operand holds every input column exactly once (mlp_plan.h
+                                // feat_quad_col), the volume quads share a round with views only at lane groups
+                                // 2 and 3, and no round after the volume's holds anything
+                                if (use_feat && order == zest::ORDER_ACC) {
+                                    std::vector<int> seen(d.in_ch_feat, 0);
+                                    for (int16_t c : p.map_feat)
+                                        if (c >= 0) {
+                                            if (c >= d.in_ch_feat) return 9;
+                                            seen[c]++;
+                                        }
+                                    for (int c : seen)
+                                        if (c != 1) return 10;
+                                    const int rv = zest::feat_volume_round(V);
+                                    if (2 * (int)(p.map_feat.size() / 32) <= rv) return 11;
+                                    if (zest::feat_quad_col(8 * (rv / 2) + (rv & 1), V) != 0 ||
+                                        zest::feat_quad_col(8 * (rv / 2) + 2 + (rv & 1), V) != 4) return 12;
+                                }
                                 // a split plan doubles every tile unit and nothing else
                                 if (precision == ZEST_PREC_F16X3) {
                                     zest::MlpPlan q;

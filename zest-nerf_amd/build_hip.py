@@ -16,13 +16,15 @@ SOURCES = ["capi.hip", "composite.hip", "composite_bwd.hip", "encode.hip", "rays
            "fused.hip"]
 # fused renderer instantiations: fused_variant.hip once per (operand type, feature shape);
 # heaviest first so the pool drains evenly
-_SHAPES = [("s4d2", 4, "true", 2), ("s2d2", 2, "true", 2), ("s4d0", 4, "true", 0), ("s2d0", 2, "true", 0),
-           ("s0d0", 0, "true", 0), ("s4", 4, "false", 0), ("s2", 2, "false", 0), ("s0", 0, "false", 0)]
+_SHAPES = [("s4d2", 4, "true", 2, "false"), ("s2d2", 2, "true", 2, "false"), ("s4d0", 4, "true", 0, "false"),
+           ("s2d0", 2, "true", 0, "false"), ("s0d0", 0, "true", 0, "false"), ("s4", 4, "false", 0, "false"),
+           ("s2", 2, "false", 0, "false"), ("s0", 0, "false", 0, "false"),
+           ("s4v", 4, "false", 0, "true"), ("s2v", 2, "false", 0, "true")]     # 'v2' static nets
 _PRECS = [("x3", "ZEST_PREC_F16X3"), ("bf16", "ZEST_PREC_BF16"), ("f16", "ZEST_PREC_F16")]
 VARIANTS = [("fused_%s_%s" % (pt, tag),
              ["-DZEST_V_PTAG=%s" % pt, "-DZEST_V_EP=%s" % ep, "-DZEST_V_TAG=%s" % tag, "-DZEST_V_NTS=%d" % nts,
-              "-DZEST_V_DYN=%s" % dyn, "-DZEST_V_NTD=%d" % ntd])
-            for tag, nts, dyn, ntd in _SHAPES for pt, ep in _PRECS]
+              "-DZEST_V_DYN=%s" % dyn, "-DZEST_V_NTD=%d" % ntd, "-DZEST_V_V2=%s" % v2])
+            for tag, nts, dyn, ntd, v2 in _SHAPES for pt, ep in _PRECS]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-Wno-inline-asm",     # the LDS-DMA asm declares the reserved register m0 clobbered on purpose

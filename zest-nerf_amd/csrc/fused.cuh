@@ -34,7 +34,7 @@ struct FusedNet {                         // one MLP + its feature sources
     const float4 *imgs;                   // [V,H,W,4] or null
     const float *w2cs, *intr;             // cameras or null
     int D, Hv, Wv, V, H, W;
-    int head, v2;
+    int head, v2;                         // v2: checked against the kernel's V2S by the host
 };
 
 struct FusedArgs {
@@ -153,9 +153,49 @@ __device__ __forceinline__ void encode_pe_operand(const float (&x)[4], int grp, 
     }
 }
 
-// Feature operand (mlp_plan.hip feat_map_acc): a lane's eight values of k-tile kt are the
-// 4-channel quads q = 8 kt + 2 g and q + 1; quad 0 / 2 = volume channels 0-3 / 4-7, quad 1 / 3 =
-// source view 0 / 1, quad q >= 4 = source view q - 2.
+// One source view in the 16-bit operand modes: pixel position straight from the staged 3 x 4 matrix P = K [R | T]
+// (stage_cams) and ONE hardware reciprocal - fx = (P p)_x / (P p)_z is the reference's
+// ((q_x / q_z) / (W - 1) * 2 - 1 + 1) / 2 * (W - 1) (utils.py:262-269, 486-487) up to fp32 rounding, and its strict
+// in-frame test -1 < 2 u - 1 < 1 is 0 < fx < W - 1.  The reference's own operation order (four IEEE divisions, the
+// normalise / un-normalise round trip) matters where a rounding can flip the mask of a sample ON the frame border; it
+// is kept by zest_color_tap for the fp32-class modes.  Here it would be 2/3 of the instructions of a tap whose result
+// is rounded to 8 or 11 bits.
+__device__ __forceinline__ float4 zest_color_tap_fast(const float4 *__restrict__ img, int H, int W,
+                                                      const float *__restrict__ P, float px, float py, float pz) {
+    const float4 r0 = *reinterpret_cast<const float4 *>(P), r1 = *reinterpret_cast<const float4 *>(P + 4),
+                 r2 = *reinterpret_cast<const float4 *>(P + 8);
+    const float qx = fmaf(pz, r0.z, fmaf(py, r0.y, fmaf(px, r0.x, r0.w)));
+    const float qy = fmaf(pz, r1.z, fmaf(py, r1.y, fmaf(px, r1.x, r1.w)));
+    const float qz = fmaf(pz, r2.z, fmaf(py, r2.y, fmaf(px, r2.x, r2.w)));
+    const float rz = __builtin_amdgcn_rcpf(qz);
+    float fx = qx * rz, fy = qy * rz;
+    const float wm = (float)(W - 1), hm = (float)(H - 1);
+    const float mask = (fx > 0.0f && fx < wm && fy > 0.0f && fy < hm) ? 1.0f : 0.0f;
+    fx = fminf(fmaxf(fx, 0.0f), wm), fy = fminf(fmaxf(fy, 0.0f), hm);       // padding_mode='border'; NaN -> 0
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const float tx = fx - x0f, ty = fy - y0f;
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const int i00 = y0 * W + x0, dx = x0 + 1 < W ? 1 : 0, dy = y0 + 1 < H ? W : 0;
+#ifdef ZEST_EXPERIMENT_TAP_SAME
+    const float4 a = img[i00 & 0], b = img[(i00 + dx) & 0], d = img[(i00 + dy) & 0], e = img[(i00 + dy + dx) & 0];
+#else
+    const float4 a = img[i00], b = img[i00 + dx], d = img[i00 + dy], e = img[i00 + dy + dx];
+#endif
+    const float w00 = (1.0f - tx) * (1.0f - ty), w10 = tx * (1.0f - ty), w01 = (1.0f - tx) * ty, w11 = tx * ty;
+    float4 o;
+    o.x = fmaf(w11, e.x, fmaf(w01, d.x, fmaf(w10, b.x, w00 * a.x)));
+    o.y = fmaf(w11, e.y, fmaf(w01, d.y, fmaf(w10, b.y, w00 * a.y)));
+    o.z = fmaf(w11, e.z, fmaf(w01, d.z, fmaf(w10, b.z, w00 * a.z)));
+    o.w = mask;
+    return o;
+}
+
+// Feature operand (mlp_plan.h feat_quad_col): a lane's eight values of k-tile kt are the 4-channel quads
+// q = 8 kt + 2 g and q + 1, filled in ROUNDS r = 2 kt + (q & 1) of one quad per lane group.  Rounds below
+// rv = feat_volume_round(V) hold source views 4 r + g: one bilinear colour tap per lane, the same instructions for
+// all 64 lanes; round rv holds the encoding volume's two channel quads at groups 0, 1 and up to two more views at
+// groups 2, 3; later rounds are empty and cost nothing (all of this is wave-uniform: V is a kernel argument).
+// 8 views: two rounds of colour taps and the trilinear lookup; 4 views (the dynamic net): one and the lookup.
 template <int EP, int NK>
 __device__ __forceinline__ void encode_feat_operand(const FusedNet &n, const float *cams_lds,
                                                     const float (&ndc)[4], const float (&pw)[3],
@@ -165,23 +205,34 @@ __device__ __forceinline__ void encode_feat_operand(const FusedNet &n, const flo
     for (int i = 0; i < NK * 8; i++) v[i] = 0.0f;
     auto view_tap = [&](int view, float *dst) {       // view >= V: clamped address, result dropped
         const int vc = view < n.V ? view : n.V - 1;
-        ZestCam cam;
         const float *cl = cams_lds + vc * kCamStride;
+        float4 o;
+        if constexpr (EP == ZEST_PREC_F16X3) {
+            ZestCam cam;
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
+            for (int i = 0; i < 3; i++) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) cam.r[i][j] = cl[4 * i + j];
+                for (int j = 0; j < 4; j++) cam.r[i][j] = cl[4 * i + j];
 #pragma unroll
-            for (int j = 0; j < 3; j++) cam.k[i][j] = cl[12 + 3 * i + j];
+                for (int j = 0; j < 3; j++) cam.k[i][j] = cl[12 + 3 * i + j];
+            }
+#ifdef ZEST_EXPERIMENT_TAP_SAME        // timing experiment only: every tap reads pixel 0 of view 0 (arithmetic kept, memory trivial)
+            o = zest_color_tap<true>(n.imgs, n.H, n.W, cam, pw[0], pw[1], pw[2]);
+#else
+            o = zest_color_tap(n.imgs + (size_t)vc * n.H * n.W, n.H, n.W, cam, pw[0], pw[1], pw[2]);
+#endif
+        } else {
+            o = zest_color_tap_fast(n.imgs + vc * (n.H * n.W), n.H, n.W, cl, pw[0], pw[1], pw[2]);
         }
-        const float4 o = zest_color_tap(n.imgs + (size_t)vc * n.H * n.W, n.H, n.W, cam, pw[0], pw[1], pw[2]);
         const bool on = view < n.V;
         dst[0] = on ? o.x : 0.f, dst[1] = on ? o.y : 0.f, dst[2] = on ? o.z : 0.f, dst[3] = on ? o.w : 0.f;
     };
 #ifdef ZEST_EXPERIMENT_NO_GATHER      // timing experiment only: features are zero
     valid = false;
 #endif
+    const int rv = feat_volume_round(n.V);
     if (valid) {
+        float vv[4] = {0.f, 0.f, 0.f, 0.f};
         if (grp < 2) {
             // Trilinear lookup of this group's four channels.  Branch-free: out-of-volume corners
             // read a clamped address with weight 0, so all eight 16-byte loads are in flight
@@ -204,21 +255,27 @@ __device__ __forceinline__ void encode_feat_operand(const FusedNet &n, const flo
                 const int xc = min(max(xi, 0), n.Wv - 1), yc = min(max(yi, 0), n.Hv - 1),
                           zc = min(max(zi, 0), n.D - 1);
                 wgt[c] = ok ? (dx ? tx : 1.0f - tx) * (dy ? ty : 1.0f - ty) * (dz ? tz : 1.0f - tz) : 0.0f;
+#ifdef ZEST_EXPERIMENT_TAP_SAME
+                tap[c] = n.vol[(((yc * n.Wv + xc) * n.D + zc) & 0) + grp];
+#else
                 tap[c] = n.vol[2 * ((yc * n.Wv + xc) * n.D + zc) + grp];      // zest_vox, 32-bit (checked by the host)
+#endif
             }
 #pragma unroll
             for (int c = 0; c < 8; c++) {
-                v[0] = fmaf(wgt[c], tap[c].x, v[0]), v[1] = fmaf(wgt[c], tap[c].y, v[1]);
-                v[2] = fmaf(wgt[c], tap[c].z, v[2]), v[3] = fmaf(wgt[c], tap[c].w, v[3]);
+                vv[0] = fmaf(wgt[c], tap[c].x, vv[0]), vv[1] = fmaf(wgt[c], tap[c].y, vv[1]);
+                vv[2] = fmaf(wgt[c], tap[c].z, vv[2]), vv[3] = fmaf(wgt[c], tap[c].w, vv[3]);
             }
-        } else {
-            view_tap(2 * grp - 2, v);                      // quads 4, 6 = views 2, 4
         }
-        view_tap(grp < 2 ? grp : 2 * grp - 1, v + 4);      // quads 1, 3, 5, 7 = views 0, 1, 3, 5
 #pragma unroll
-        for (int t = 1; t < NK; t++) {                     // quads 8 t + 2 g (+ 1) = views 8 t + 2 g - 2 (- 1)
-            view_tap(8 * t + 2 * grp - 2, v + 8 * t);
-            view_tap(8 * t + 2 * grp - 1, v + 8 * t + 4);
+        for (int r = 0; r < 2 * NK; r++) {
+            float *dst = v + 8 * (r >> 1) + 4 * (r & 1);
+            if (r < rv) {
+                view_tap(4 * r + grp, dst);
+            } else if (r == rv) {
+                if (n.V > 4 * rv) view_tap(grp >= 2 ? 4 * rv + grp - 2 : n.V, dst);     // at most views 4 rv, 4 rv + 1
+                if (grp < 2) dst[0] = vv[0], dst[1] = vv[1], dst[2] = vv[2], dst[3] = vv[3];
+            }
         }
     }
 #pragma unroll
@@ -230,14 +287,28 @@ __device__ __forceinline__ void encode_feat_operand(const FusedNet &n, const flo
     }
 }
 
+// Cameras of a net's source views -> LDS, kCamStride floats per view: the rows of w2c[:3, :4] and K (fp32-class mode:
+// the reference's two-stage projection) or, PROJ, the product P = K [R | T] (12 floats, zest_color_tap_fast); the
+// first view's rotation rows are read by zest_view_dir in both forms, so PROJ keeps them at floats 12 .. 23.
+template <bool PROJ>
 __device__ __forceinline__ void stage_cams(const FusedNet &n, float *lds) {
     if (!n.w2cs) return;
     const int nv = n.imgs ? n.V : 1;
     for (int i = threadIdx.x; i < nv * kCamStride; i += blockDim.x) {
         const int v = i / kCamStride, k = i % kCamStride;
         float val = 0.0f;
-        if (k < 12) val = n.w2cs[16 * v + k];
-        else if (k < 21 && n.intr) val = n.intr[9 * v + (k - 12)];
+        if constexpr (PROJ) {
+            if (k < 12 && n.intr) {
+                const int row = k >> 2, col = k & 3;
+                const float *K = n.intr + 9 * v + 3 * row, *Rt = n.w2cs + 16 * v + col;
+                val = fmaf(K[2], Rt[8], fmaf(K[1], Rt[4], K[0] * Rt[0]));
+            } else if (k >= 12) {
+                val = n.w2cs[16 * v + (k - 12)];
+            }
+        } else {
+            if (k < 12) val = n.w2cs[16 * v + k];
+            else if (k < 21 && n.intr) val = n.intr[9 * v + (k - 12)];
+        }
         lds[i] = val;
     }
 }
@@ -301,7 +372,8 @@ __device__ __forceinline__ float block_excl_prod(float f, int c, float *total) {
 #ifndef ZEST_EARLY_DYN_GATHER
 #define ZEST_EARLY_DYN_GATHER 0    // 1: the dynamic net's gathers are issued at the start of the pass, operand parked in LDS
 #endif
-template <int EP, int NT_FEAT_S, bool DYN, int NT_FEAT_D>
+// V2S: the static net is a 'v2' net (additive modulation; only single-net kernels with features are built for it)
+template <int EP, int NT_FEAT_S, bool DYN, int NT_FEAT_D, bool V2S = false>
 __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_CU / 4) void fused_blocks_kernel(FusedArgs a) {
     constexpr bool MOD_S = NT_FEAT_S > 0, MOD_D = NT_FEAT_D > 0;
     constexpr int NP = ep_parts(EP), CB = fused_cb(EP), BS = 16 * CB;
@@ -321,8 +393,9 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
     static_assert(sizeof(lds) <= 163840, "LDS budget of one workgroup per CU");
     float *cams_s = reinterpret_cast<float *>(lds + kRingUnits * 1024), *cams_d = cams_s + kMaxViews * kCamStride;
     float2 *zd_lds = reinterpret_cast<float2 *>(cams_d + kMaxViews * kCamStride);
-    stage_cams(a.st, cams_s);
-    if (DYN) stage_cams(a.dy, cams_d);
+    constexpr bool PROJ = EP != ZEST_PREC_F16X3;         // 16-bit operand modes: fast projection
+    stage_cams<PROJ>(a.st, cams_s);
+    if (DYN) stage_cams<PROJ>(a.dy, cams_d);
     int *ring_flags = reinterpret_cast<int *>(zd_lds + kFusedWaves * 32);
     float *rec_lds = reinterpret_cast<float *>(ring_flags + 2 * kSlots);      // [waves][kPartialFloats]
     float4 *x_lds = reinterpret_cast<float4 *>(rec_lds + kFusedWaves * kPartialFloats);    // [waves][32]
@@ -434,7 +507,7 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
             return [&, cams](OpArr<1, NP> (&views)[CB]) {
                 const float *dir = a.dir + 3 * (g >= 0 ? g / a.bpr : 0);
                 float dv[4] = {0.f, 0.f, 0.f, 0.f};
-                zest_view_dir(dir, n.w2cs ? cams : nullptr, dv);
+                zest_view_dir(dir, n.w2cs ? cams + (PROJ ? 12 : 0) : nullptr, dv);
                 encode_pe_operand<EP, 3, 4, 1>(dv, grp, views[0]);
 #pragma unroll
                 for (int cb = 1; cb < CB; cb++) views[cb] = views[0];          // one ray per block
@@ -498,7 +571,7 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
         };
         ZEST_STAMP(st_enc);
         if constexpr (ZEST_REBUILD_PTS) {
-            engine_forward<EP, CB, 4, MOD_S, NT_FEAT_S>(tiles, unit, a.st.v2 != 0, pts_static, feat_s,
+            engine_forward<EP, CB, 4, MOD_S, NT_FEAT_S, V2S>(tiles, unit, pts_static, feat_s,
                                                         views_of(a.st, cams_s), head_s, rgb_s);
         } else {
             OpArr<2, NP> pts_keep[CB];
@@ -507,7 +580,7 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
 #pragma unroll
                 for (int cb = 0; cb < CB; cb++) o[cb] = pts_keep[cb];
             };
-            engine_forward<EP, CB, 4, MOD_S, NT_FEAT_S>(tiles, unit, a.st.v2 != 0, pts_copy, feat_s,
+            engine_forward<EP, CB, 4, MOD_S, NT_FEAT_S, V2S>(tiles, unit, pts_copy, feat_s,
                                                         views_of(a.st, cams_s), head_s, rgb_s);
         }
         ZEST_STAMP(st_eng);
@@ -523,7 +596,7 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
             zz = zd.x, dist = fmaxf(zd.y, 0.0f), valid = zd.y >= 0.0f;
             float sg = join(head_s, 0);
             cr = join(rgb_s, 0), cg = join(rgb_s, 1), cb = join(rgb_s, 2);
-            if (a.st.v2) {   // 'v2' nets activate inside the network; the compositor does it again
+            if (V2S) {       // 'v2' nets activate inside the network; the compositor does it again
                 cr = zest_sigmoid(cr), cg = zest_sigmoid(cg), cb = zest_sigmoid(cb), sg = fmaxf(sg, 0.f);
             }
             cr = zest_sigmoid(cr), cg = zest_sigmoid(cg), cb = zest_sigmoid(cb);
@@ -564,7 +637,7 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
             }
             ZEST_STAMP(st_comp);
             if constexpr (ZEST_REBUILD_PTS) {
-                engine_forward<EP, CB, 6, MOD_D, NT_FEAT_D>(tiles, unit, false, pts_dynamic, feat_d,
+                engine_forward<EP, CB, 6, MOD_D, NT_FEAT_D, false>(tiles, unit, pts_dynamic, feat_d,
                                                             views_of(a.dy, cams_d), head_d, rgb_d);
             } else {
                 OpArr<3, NP> pts_keep[CB];
@@ -573,7 +646,7 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
 #pragma unroll
                     for (int cb = 0; cb < CB; cb++) o[cb] = pts_keep[cb];
                 };
-                engine_forward<EP, CB, 6, MOD_D, NT_FEAT_D>(tiles, unit, false, pts_copy, feat_d,
+                engine_forward<EP, CB, 6, MOD_D, NT_FEAT_D, false>(tiles, unit, pts_copy, feat_d,
                                                             views_of(a.dy, cams_d), head_d, rgb_d);
             }
             ZEST_STAMP(st_eng);
@@ -650,10 +723,10 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
 }
 
 // one translation unit per variant (fused_*.hip) so they compile in parallel
-#define ZEST_FUSED_VARIANT(ptag, EP, tag, NTS, DYN, NTD) ZEST_FUSED_VARIANT_(ptag, EP, tag, NTS, DYN, NTD)
-#define ZEST_FUSED_VARIANT_(ptag, EP, tag, NTS, DYN, NTD)                                        \
+#define ZEST_FUSED_VARIANT(ptag, EP, tag, NTS, DYN, NTD, V2S) ZEST_FUSED_VARIANT_(ptag, EP, tag, NTS, DYN, NTD, V2S)
+#define ZEST_FUSED_VARIANT_(ptag, EP, tag, NTS, DYN, NTD, V2S)                                   \
     int fused_launch_##ptag##_##tag(const FusedArgs &a, int blocks, hipStream_t stream) {        \
-        hipLaunchKernelGGL((fused_blocks_kernel<EP, NTS, DYN, NTD>), dim3(blocks),               \
+        hipLaunchKernelGGL((fused_blocks_kernel<EP, NTS, DYN, NTD, V2S>), dim3(blocks),          \
                            dim3(kFusedWaves * 64), 0, stream, a);                                \
         ZEST_RETURN_LAUNCH("zest_render_fused_fwd(" #ptag "_" #tag ")");                         \
     }                                                                                            \
@@ -673,5 +746,7 @@ ZEST_FUSED_DECL(s2d0)
 ZEST_FUSED_DECL(s4d0)
 ZEST_FUSED_DECL(s2d2)
 ZEST_FUSED_DECL(s4d2)
+ZEST_FUSED_DECL(s2v)
+ZEST_FUSED_DECL(s4v)
 
 }  // namespace zest

@@ -161,7 +161,11 @@ extern "C" int zest_render_fused_fwd(const float *ndc, const float *pts, const f
     int blocks = 0;                        // workgroups: at most one per CU (128 KiB ring)
     zest_render_fused_pass_shape(R, S, precision, cus, &a.ray_ranges, &blocks, nullptr);
     hipStream_t st = (hipStream_t)stream;
-    const int key = (dyn ? 100 : 0) + nts * 10 + ntd;
+    // 'v2' static nets (additive modulation) have kernels of their own, single-net only
+    const bool v2s = a.st.v2 != 0;
+    ZEST_CHECK_ARG(!(v2s && (dyn || nts == 0)),
+                   "zest_render_fused_fwd: a 'v2' net is rendered by the single-net kernels with features only");
+    const int key = (v2s ? 1000 : 0) + (dyn ? 100 : 0) + nts * 10 + ntd;
     int rc = -1;
 #define ZEST_CASE1(ptag, tag)                                                                    \
     ZEST_CHECK_ARG(zest::fused_units_##ptag##_##tag(0) == units_s && zest::fused_units_##ptag##_##tag(1) == units_d, \
@@ -183,6 +187,8 @@ extern "C" int zest_render_fused_fwd(const float *ndc, const float *pts, const f
         ZEST_CASE(140, s4d0)
         ZEST_CASE(122, s2d2)
         ZEST_CASE(142, s4d2)
+        ZEST_CASE(1020, s2v)
+        ZEST_CASE(1040, s4v)
         default:
             zest_set_error("zest_render_fused_fwd: no fused variant for %d static / %d dynamic feature "
                            "tiles%s", nts, ntd, dyn ? "" : " (static only)");

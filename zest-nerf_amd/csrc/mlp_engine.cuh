@@ -475,9 +475,15 @@ struct NoSink {
     __device__ __forceinline__ void operator()(int, int, int, const float (&)[8]) const {}
 };
 
-template <int EP, int CB, int NJB, int NKA, int NKB, bool MOD, int NKF, bool RELU, int MODE, class Tiles,
+// V2: additive modulation (Renderer_linear, networks.py:294) instead of the multiplicative one.  A template
+// parameter on purpose: as a launch-time flag, `v2 ? v + m : v * m` per element makes hipcc compute both and select -
+// three vector instructions per value where one is needed, 2 048 of the ~5 500 a feature pass issued beside its
+// 2 880 MFMAs, on the port the engine is short of (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost') - and a
+// scalar branch per row block cuts the unrolled network into basic blocks the register allocator answers with
+// ~200 spills.
+template <int EP, int CB, int NJB, int NKA, int NKB, bool MOD, int NKF, bool RELU, int MODE, bool V2, class Tiles,
           class Sink = NoSink>
-__device__ __forceinline__ void engine_layer(const Tiles &tiles, int &unit, bool v2,
+__device__ __forceinline__ void engine_layer(const Tiles &tiles, int &unit,
                                              const OpArr<NKA, ep_parts(EP)> (&opa)[CB],
                                              const OpArr<NKB, ep_parts(EP)> (&opb)[CB],
                                              const OpArr<NKF, ep_parts(EP)> (&opf)[CB],
@@ -569,12 +575,18 @@ __device__ __forceinline__ void engine_layer(const Tiles &tiles, int &unit, bool
             for (int i = 0; i < 8; i++) {
                 v[i] = acc[i >> 2][cb][i & 3];
                 if (X3) v[i] = fmaf(corr[i >> 2][cb][i & 3], kLoUnscale, v[i]);
-                if (MOD) {
+            }
+            if (MOD) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
                     float mv = macc[i >> 2][cb][i & 3];
                     if (X3) mv = fmaf(mcorr[i >> 2][cb][i & 3], kLoUnscale, mv);
-                    v[i] = v2 ? v[i] + mv : v[i] * mv;
+                    v[i] = V2 ? v[i] + mv : v[i] * mv;
                 }
-                if (RELU && !kPackedRelu) v[i] = relu1<EP>(v[i]);
+            }
+            if (RELU && !kPackedRelu) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) v[i] = relu1<EP>(v[i]);
             }
             if (MODE == 0) {
                 if constexpr (kPackedRelu) store_tile_relu16<EP>(v, out[cb], jb);
@@ -595,8 +607,8 @@ __device__ __forceinline__ void engine_layer(const Tiles &tiles, int &unit, bool
 // out copies);
 // `views_fn(views)` builds the direction operand when it is first needed (op 10).  Results per column block: head (lane group g: rows 4g .. 4g+3 of the head
 // tile; row 0 alpha, rows 1.. extra heads) and rgb (group 0: rows 0-2), raw.
-template <int EP, int CB, int NU_PTS, bool MOD, int NU_FEAT, class Tiles, class PtsFn, class ViewsFn, class Sink = NoSink>
-__device__ __forceinline__ void engine_forward(const Tiles &tiles, int &unit, bool v2, PtsFn pts_fn,
+template <int EP, int CB, int NU_PTS, bool MOD, int NU_FEAT, bool V2, class Tiles, class PtsFn, class ViewsFn, class Sink = NoSink>
+__device__ __forceinline__ void engine_forward(const Tiles &tiles, int &unit, PtsFn pts_fn,
                                                const OpArr<NU_FEAT / 2, ep_parts(EP)> (&feat)[CB], ViewsFn views_fn,
                                                f32x4 (&head)[CB], f32x4 (&rgb)[CB], const Sink &sink = Sink()) {
     constexpr int KP = NU_PTS / 2, KF = NU_FEAT / 2, NP = ep_parts(EP);
@@ -608,27 +620,27 @@ __device__ __forceinline__ void engine_forward(const Tiles &tiles, int &unit, bo
     {
         OpArr<KP, NP> pts[CB];
         pts_fn(pts, 0);
-        engine_layer<EP, CB, 8, KP, 0, MOD, KF, true, 0>(tiles, unit, v2, pts, none, feat, hA, unused, 0, sink);
+        engine_layer<EP, CB, 8, KP, 0, MOD, KF, true, 0, V2>(tiles, unit, pts, none, feat, hA, unused, 0, sink);
     }
-    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hA, none, feat, hB, unused, 1, sink);
-    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hB, none, feat, hA, unused, 2, sink);
-    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hA, none, feat, hB, unused, 3, sink);
-    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hB, none, feat, hA, unused, 4, sink);
+    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0, V2>(tiles, unit, hA, none, feat, hB, unused, 1, sink);
+    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0, V2>(tiles, unit, hB, none, feat, hA, unused, 2, sink);
+    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0, V2>(tiles, unit, hA, none, feat, hB, unused, 3, sink);
+    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0, V2>(tiles, unit, hB, none, feat, hA, unused, 4, sink);
     {
         // `token` is a value layer 4 has just produced: a builder that ties its address arithmetic to it
         // cannot be scheduled ahead of layers 1-4 (where its registers would be live all along)
         OpArr<KP, NP> pts[CB];
         pts_fn(pts, (int)hA[CB - 1].t[0][7][0]);
-        engine_layer<EP, CB, 8, KP, 8, MOD, KF, true, 0>(tiles, unit, v2, pts, hA, feat, hB, unused, 5, sink);
+        engine_layer<EP, CB, 8, KP, 8, MOD, KF, true, 0, V2>(tiles, unit, pts, hA, feat, hB, unused, 5, sink);
     }
-    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hB, none, feat, hA, unused, 6, sink);
-    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0>(tiles, unit, v2, hA, none, feat, hB, unused, 7, sink);
+    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0, V2>(tiles, unit, hB, none, feat, hA, unused, 6, sink);
+    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0, V2>(tiles, unit, hA, none, feat, hB, unused, 7, sink);
     // trunk output in hB
-    engine_layer<EP, CB, 1, 8, 0, false, KF, false, 1>(tiles, unit, v2, hB, none, feat, hA, head);
-    engine_layer<EP, CB, 8, 8, 0, false, KF, false, 0>(tiles, unit, v2, hB, none, feat, hA, unused, 8, sink);
+    engine_layer<EP, CB, 1, 8, 0, false, KF, false, 1, V2>(tiles, unit, hB, none, feat, hA, head);
+    engine_layer<EP, CB, 8, 8, 0, false, KF, false, 0, V2>(tiles, unit, hB, none, feat, hA, unused, 8, sink);
     OpArr<1, NP> views[CB];
     views_fn(views);
-    engine_layer<EP, CB, 4, 8, 1, false, KF, true, 0>(tiles, unit, v2, hA, views, feat, hB, unused, 9, sink);
+    engine_layer<EP, CB, 4, 8, 1, false, KF, true, 0, V2>(tiles, unit, hA, views, feat, hB, unused, 9, sink);
     // rgb: 128 hidden features = first 4 k-tiles of hB
     OpArr<4, NP> h128[CB];
 #pragma unroll
@@ -637,7 +649,7 @@ __device__ __forceinline__ void engine_forward(const Tiles &tiles, int &unit, bo
         for (int pt = 0; pt < NP; pt++)
 #pragma unroll
             for (int k = 0; k < 4; k++) h128[cb].t[pt][k] = hB[cb].t[pt][k];
-    engine_layer<EP, CB, 1, 4, 0, false, KF, false, 1>(tiles, unit, v2, h128, none, feat, hA, rgb);
+    engine_layer<EP, CB, 1, 4, 0, false, KF, false, 1, V2>(tiles, unit, h128, none, feat, hA, rgb);
     tiles.finish(unit, unit0 + stream_units(NU_PTS, MOD ? NU_FEAT : 0, NP));
     unit = unit0 + stream_units(NU_PTS, MOD ? NU_FEAT : 0, NP);
 }

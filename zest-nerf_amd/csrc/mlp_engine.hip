@@ -55,9 +55,9 @@ struct StashSink {
     }
 };
 
-template <int EP, int NT_PTS, bool MOD, int NT_FEAT, bool TRAIN = false>
+template <int EP, int NT_PTS, bool MOD, int NT_FEAT, bool TRAIN = false, bool V2 = false>
 __global__ __launch_bounds__(kMlpWaves * 64, kMlpWaves / 4) void mlp_engine_kernel(
-    const uint4 *__restrict__ tiles_g, const float *__restrict__ x, int M, int P, int F, int C_in, int C_out, int head, int v2,
+    const uint4 *__restrict__ tiles_g, const float *__restrict__ x, int M, int P, int F, int C_in, int C_out, int head,
     int act_out, float *__restrict__ out, uint4 *__restrict__ stash_tiles = nullptr, uint2 *__restrict__ stash_masks = nullptr) {
     constexpr int NP = ep_parts(EP), CB = mlp_cb(EP), UNITS = stream_units(NT_PTS, MOD ? NT_FEAT : 0, NP);
     using Ring = RingTiles<kMlpWaves, UNITS, 0>;
@@ -129,9 +129,9 @@ __global__ __launch_bounds__(kMlpWaves * 64, kMlpWaves / 4) void mlp_engine_kern
         };
         if constexpr (TRAIN) {
             const StashSink<CB> sink{stash_tiles, stash_masks, (long long)pass * kMlpWaves + wave, lane, {}, {}};
-            engine_forward<EP, CB, NT_PTS, MOD, NT_FEAT>(tiles, unit, v2 != 0, pts_fn, feat, views_fn, headt, rgbt, sink);
+            engine_forward<EP, CB, NT_PTS, MOD, NT_FEAT, V2>(tiles, unit, pts_fn, feat, views_fn, headt, rgbt, sink);
         } else {
-            engine_forward<EP, CB, NT_PTS, MOD, NT_FEAT>(tiles, unit, v2 != 0, pts_fn, feat, views_fn, headt, rgbt);
+            engine_forward<EP, CB, NT_PTS, MOD, NT_FEAT, V2>(tiles, unit, pts_fn, feat, views_fn, headt, rgbt);
         }
 #pragma unroll
         for (int cb = 0; cb < CB; cb++) {
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(kMlpWaves * 64, kMlpWaves / 4) void mlp_engine_kern
     tiles.drain();
 }
 
-template <int EP, int NT_PTS, bool MOD, int NT_FEAT, bool TRAIN = false>
+template <int EP, int NT_PTS, bool MOD, int NT_FEAT, bool TRAIN = false, bool V2 = false>
 static int launch_one(const MlpPlan &p, const void *tiles, const float *x, int M,
                       float *out, hipStream_t stream, void *stash_tiles = nullptr, void *stash_masks = nullptr) {
     constexpr int units = stream_units(NT_PTS, MOD ? NT_FEAT : 0, ep_parts(EP));
@@ -177,9 +177,13 @@ static int launch_one(const MlpPlan &p, const void *tiles, const float *x, int M
         cus = 256;
     const int n_pass = zest_div_up(zest_div_up(M, 16 * mlp_cb(EP)), kMlpWaves);
     const int blocks = n_pass < cus ? n_pass : cus;             // one workgroup per CU (128 KiB ring)
-    hipLaunchKernelGGL((mlp_engine_kernel<EP, NT_PTS, MOD, NT_FEAT, TRAIN>), dim3(blocks), dim3(kMlpWaves * 64), 0, stream,
+    if ((d.net_type >= 2) != V2) {
+        zest_set_error("zest_mlp_fwd(engine): kernel / net_type mismatch");
+        return (int)hipErrorInvalidValue;
+    }
+    hipLaunchKernelGGL((mlp_engine_kernel<EP, NT_PTS, MOD, NT_FEAT, TRAIN, V2>), dim3(blocks), dim3(kMlpWaves * 64), 0, stream,
                        (const uint4 *)tiles, x, M, d.in_ch_pts, F, C_in, C_out, d.head,
-                       d.net_type >= 2 ? 1 : 0, d.net_type == 2 ? 1 : 0, out, (uint4 *)stash_tiles, (uint2 *)stash_masks);
+                       d.net_type == 2 ? 1 : 0, out, (uint4 *)stash_tiles, (uint2 *)stash_masks);
     ZEST_RETURN_LAUNCH(TRAIN ? "zest_mlp_train16_fwd" : "zest_mlp_fwd(engine)");
 }
 
@@ -187,6 +191,17 @@ template <int EP>
 static int launch_prec(const MlpPlan &p, const void *tiles, const float *x, int M, float *out, hipStream_t stream) {
     const bool mod = p.desc.use_feat != 0;
     const int key = p.nt_pts * 10 + (mod ? p.nt_feat : 0);
+    if (p.desc.net_type >= 2) {       // additive modulation ('v2' trunk): always with features, static nets (63 point channels)
+        switch (key) {
+            case 42: return launch_one<EP, 4, true, 2, false, true>(p, tiles, x, M, out, stream);
+            case 44: return launch_one<EP, 4, true, 4, false, true>(p, tiles, x, M, out, stream);
+            case 62: return launch_one<EP, 6, true, 2, false, true>(p, tiles, x, M, out, stream);
+            case 64: return launch_one<EP, 6, true, 4, false, true>(p, tiles, x, M, out, stream);
+        }
+        zest_set_error("zest_mlp_fwd(engine): no 'v2' kernel for %d point units / %d feature units per row block",
+                       p.nt_pts, mod ? p.nt_feat : 0);
+        return (int)hipErrorInvalidValue;
+    }
     switch (key) {
         case 40: return launch_one<EP, 4, false, 0>(p, tiles, x, M, out, stream);
         case 42: return launch_one<EP, 4, true, 2>(p, tiles, x, M, out, stream);

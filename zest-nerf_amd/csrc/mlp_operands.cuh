@@ -11,8 +11,7 @@ namespace zest {
 //   PE operand of C coordinates, L bands: element e of k-tile kt is m = 8 kt + e;
 //     m < (L/2) C:  column C + 2C (2 (m / C) + (g >> 1)) + (g & 1) C + m % C
 //                   = [C + 4C (m / C) + m % C] + [(g >> 1) 2C + (g & 1) C];   m = (L/2) C: column g (< C)
-//   feature operand: quad q = 8 kt + 2 g + (e >> 2), channel c = e & 3:
-//     q = 0, 2: volume columns c, 4 + c;  q = 1, 3: columns 8 + c, 12 + c;  q >= 4: column 4 q + c
+//   feature operand: quad q = 8 kt + 2 g + (e >> 2), channel c = e & 3: column feat_quad_col(q, V) + c (mlp_plan.h)
 template <int EP, int C, int L, int NK>
 __device__ __forceinline__ void load_pe_operand(const float *__restrict__ xrow, bool valid, int grp,
                                                 OpArr<NK, ep_parts(EP)> &op) {
@@ -36,17 +35,12 @@ __device__ __forceinline__ void load_pe_operand(const float *__restrict__ xrow, 
 template <int EP, int NK>
 __device__ __forceinline__ void load_feat_operand(const float *__restrict__ xf, int F, bool valid, int grp,
                                                   OpArr<NK, ep_parts(EP)> &op) {
+    const int V = (F - 8) / 4;
 #pragma unroll
     for (int t = 0; t < NK; t++) {
         // first columns of this lane's two quads
-        int ca, cb;
-        if (t == 0) {
-            ca = grp == 0 ? 0 : (grp == 1 ? 4 : 8 * grp);              // quads 0, 2, 4, 6
-            cb = grp == 0 ? 8 : (grp == 1 ? 12 : 8 * grp + 4);         // quads 1, 3, 5, 7
-        } else {
-            ca = 32 * t + 8 * grp, cb = ca + 4;
-        }
-        const bool va = valid && ca + 4 <= F, vb = valid && cb + 4 <= F;
+        const int ca = feat_quad_col(8 * t + 2 * grp, V), cb = feat_quad_col(8 * t + 2 * grp + 1, V);
+        const bool va = valid && ca >= 0, vb = valid && cb >= 0;
         const float *pa = xf + (va ? ca : 0), *pb = xf + (vb ? cb : 0);
         float v[8];
 #pragma unroll
@@ -74,14 +68,9 @@ __device__ __forceinline__ void load_pe_tile_raw(const float *__restrict__ xrow,
 }
 
 __device__ __forceinline__ void load_feat_tile_raw(const float *__restrict__ xf, int F, bool valid, int grp, int t, float (&v)[8]) {
-    int ca, cb;
-    if (t == 0) {
-        ca = grp == 0 ? 0 : (grp == 1 ? 4 : 8 * grp);
-        cb = grp == 0 ? 8 : (grp == 1 ? 12 : 8 * grp + 4);
-    } else {
-        ca = 32 * t + 8 * grp, cb = ca + 4;
-    }
-    const bool va = valid && ca + 4 <= F, vb = valid && cb + 4 <= F;
+    const int V = (F - 8) / 4;
+    const int ca = feat_quad_col(8 * t + 2 * grp, V), cb = feat_quad_col(8 * t + 2 * grp + 1, V);
+    const bool va = valid && ca >= 0, vb = valid && cb >= 0;
     const float *pa = xf + (va ? ca : 0), *pb = xf + (vb ? cb : 0);
 #pragma unroll
     for (int c = 0; c < 4; c++) v[c] = va ? pa[c] : 0.0f, v[4 + c] = vb ? pb[c] : 0.0f;

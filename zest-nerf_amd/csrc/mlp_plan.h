@@ -47,7 +47,34 @@
 #include <vector>
 #include "../../include/zest_render.h"
 
+#ifdef __HIPCC__
+#define ZEST_HD __host__ __device__
+#else
+#define ZEST_HD
+#endif
+
 namespace zest {
+
+// ---- feature operand of the register engine (ORDER_ACC): which four input columns a QUAD holds ----------------
+// The operand is a sequence of k-tiles of 8 quads (4 channels each); lane group g holds quads 8 kt + 2 g and
+// 8 kt + 2 g + 1 of k-tile kt, so the four groups fill the operand in ROUNDS r = 2 kt + j of four quads (j = q & 1),
+// one per group - and in the fused renderer a round is one gather step that all 64 lanes execute together.  The
+// quads are therefore dealt so that the lanes of a round do the SAME kind of work: source view v of the V views
+// (input columns 8 + 4 v ..) sits in round v / 4 at group v % 4 for the first 4 rv views; the two channel quads of the
+// encoding volume (columns 0-3, 4-7) sit in round rv at groups 0 and 1, next to at most two more views at groups 2
+// and 3 (rv = V / 4, or V / 4 + 1 when three views would be left over).  8 views: two rounds of four bilinear
+// colour taps, one round with the trilinear lookup alone, nothing in the fourth (rounds 1-2 dealt the quads
+// [vol | view] [view] [view] [view]: five serial steps, two of them for views that do not exist).
+// -> first input column of quad q (channels col .. col + 3), or -1 for an all-zero quad.  One definition for the plan
+// builder (weight packing), the operand loaders of the standalone / training kernels and the fused gather.
+ZEST_HD inline int feat_volume_round(int V) { return V % 4 <= 2 ? V / 4 : V / 4 + 1; }
+ZEST_HD inline int feat_quad_col(int q, int V) {
+    const int r = 2 * (q >> 3) + (q & 1), g = (q & 7) >> 1, rv = feat_volume_round(V);
+    if (r > rv) return -1;
+    if (r == rv && g < 2) return 4 * g;
+    const int view = r < rv ? 4 * r + g : 4 * rv + g - 2;
+    return view < V ? 8 + 4 * view : -1;
+}
 
 constexpr int kW = 256;            // default trunk width (every shipped config: netwidth = 256), the engine's only one
 constexpr int kNumOps = 12;        // op slots: depth <= 8

@@ -29,18 +29,14 @@ void pe_map_acc(int C, int L, int npos, std::vector<int16_t> &m) {
     }
 }
 
-// feature operand: 4-channel quads, quad index 8*kt + 2*g + (e >> 2):
-// 0 = volume channels 0-3, 2 = volume channels 4-7, 1 = view 0, 3 = view 1, q >= 4 = view q-2
+// feature operand: 4-channel quads, quad index 8*kt + 2*g + (e >> 2); which columns a quad holds: mlp_plan.h
+// feat_quad_col
 void feat_map_acc(int V, int npos, std::vector<int16_t> &m) {
     m.assign((size_t)npos, -1);
     for (int pos = 0; pos < npos; pos++) {
         const int kt = pos / 32, g = (pos % 32) / 8, e = pos % 8, q = 8 * kt + 2 * g + (e >> 2), c = e & 3;
-        if (q == 0) m[pos] = (int16_t)c;
-        else if (q == 2) m[pos] = (int16_t)(4 + c);
-        else {
-            const int view = q == 1 ? 0 : (q == 3 ? 1 : q - 2);
-            if (view < V) m[pos] = (int16_t)(8 + 4 * view + c);
-        }
+        const int col = feat_quad_col(q, V);
+        if (col >= 0) m[pos] = (int16_t)(col + c);
     }
 }
 

@@ -287,11 +287,10 @@ __device__ __forceinline__ int pe_col_of(int jb, int rt, int r, int grp) {
     return (mm == (L / 2) * C && g < C) ? g : -1;
 }
 __device__ __forceinline__ int feat_col_of(int jb, int rt, int r, int grp, int V) {
-    const int q = 8 * jb + 4 * rt + grp;                      // quad of four channels
-    if (q == 0) return r;
-    if (q == 2) return 4 + r;
-    const int view = q == 1 ? 0 : (q == 3 ? 1 : q - 2);
-    return view < V ? 8 + 4 * view + r : -1;
+    // accumulator row 16 rt + 4 grp + r of row block jb = operand position 32 jb + 16 rt + 4 grp + r = quad
+    // 8 jb + 4 rt + grp, channel r (mlp_plan.h feat_quad_col)
+    const int col = feat_quad_col(8 * jb + 4 * rt + grp, V);
+    return col >= 0 ? col + r : -1;
 }
 
 // ------------------------------------------------------------------------------ finishing kernel

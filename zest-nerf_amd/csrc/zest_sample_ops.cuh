@@ -81,6 +81,7 @@ __device__ __forceinline__ void zest_volume_trilerp(const float4 *__restrict__ v
 
 // One source view: world point -> pixel -> bilinear rgb (border clamp) + strict in-frame mask.
 // img: [H,W,4] of this view.  out = (r, g, b, mask).
+template <bool SAME_PIXEL = false>   // SAME_PIXEL: timing experiments only (all four taps read pixel 0)
 __device__ __forceinline__ float4 zest_color_tap(const float4 *__restrict__ img, int H, int W,
                                                  const ZestCam &c, float px, float py, float pz) {
     // p_cam = R p + T, q = K p_cam (reference utils.py:262-268), fp32, left-to-right sums
@@ -100,8 +101,9 @@ __device__ __forceinline__ float4 zest_color_tap(const float4 *__restrict__ img,
     const float tx = fx - x0f, ty = fy - y0f;
     const int x0 = (int)x0f, y0 = (int)y0f;
     const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
-    const float4 a = img[(size_t)y0 * W + x0], b = img[(size_t)y0 * W + x1];
-    const float4 d = img[(size_t)y1 * W + x0], e = img[(size_t)y1 * W + x1];
+    const size_t keep = SAME_PIXEL ? 0 : ~(size_t)0;
+    const float4 a = img[((size_t)y0 * W + x0) & keep], b = img[((size_t)y0 * W + x1) & keep];
+    const float4 d = img[((size_t)y1 * W + x0) & keep], e = img[((size_t)y1 * W + x1) & keep];
     const float w00 = (1.0f - tx) * (1.0f - ty), w10 = tx * (1.0f - ty);
     const float w01 = (1.0f - tx) * ty, w11 = tx * ty;
     float4 o;

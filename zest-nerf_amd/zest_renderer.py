@@ -214,7 +214,9 @@ def rendering(args, rays_pts, rays_ndc, depth_candidates, rays_dir,
     # The engine kernels are written for the shipped MLP shape (D=8, W=256, skips=[4]); a net of another
     # shape takes the complete plan with the exact-product fp32 MLP kernel.
     engine_shape = net_s.nerf.default_shape and (network_fn_dy is None or _net(network_fn_dy, "network_fn_dy").nerf.default_shape)
-    if getattr(args, "zest_maps_only", False) and (val or not scene_flow) and not train and engine_shape:
+    # ('v2' static nets have single-net fused kernels only; next to a dynamic net they take the complete plan)
+    fused_ok = engine_shape and not (scene_flow and net_s.desc().net_type == 2)
+    if getattr(args, "zest_maps_only", False) and (val or not scene_flow) and not train and fused_ok:
         fused_prec = zest_hip.PREC_F16X3 if prec == zest_hip.PREC_F32 else prec     # no exact-product fused kernel
         return _render_maps_fused(fused_prec, time_codes, rays_ndc, ndc, pts, z, dirs, net_s, network_fn_dy, scene_flow,
                                   volume_feature_static, volume_feature_dynamic, imgs,

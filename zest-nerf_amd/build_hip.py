@@ -23,7 +23,12 @@ _SHAPES = [("s4d2", 4, "true", 2, "false"), ("s2d2", 2, "true", 2, "false"), ("s
 _PRECS = [("x3", "ZEST_PREC_F16X3"), ("bf16", "ZEST_PREC_BF16"), ("f16", "ZEST_PREC_F16")]
 VARIANTS = [("fused_%s_%s" % (pt, tag),
              ["-DZEST_V_PTAG=%s" % pt, "-DZEST_V_EP=%s" % ep, "-DZEST_V_TAG=%s" % tag, "-DZEST_V_NTS=%d" % nts,
-              "-DZEST_V_DYN=%s" % dyn, "-DZEST_V_NTD=%d" % ntd, "-DZEST_V_V2=%s" % v2])
+              "-DZEST_V_DYN=%s" % dyn, "-DZEST_V_NTD=%d" % ntd, "-DZEST_V_V2=%s" % v2] +
+             # kernels with features: no SLP vectorizer.  It fuses the modulation multiplies of the row-block
+             # epilogues into v_pk_mul_f32, which beside MFMAs costs more issue time than the two plain multiplies it
+             # replaces (MI355X_MICROARCH.md, 'price of one filler beside MFMAs'): +1.0 % / +1.8 % on the one- / two-net
+             # feature kernels, -0.7 % on the featureless one, which keeps it (profiles/r03_ab_slp_ring.txt)
+             (["-fno-slp-vectorize"] if (nts or ntd) else []))
             for tag, nts, dyn, ntd, v2 in _SHAPES for pt, ep in _PRECS]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
@@ -93,8 +98,8 @@ def build(force=False, extra_flags=(), tag=None, only=None):
 
 
 if __name__ == "__main__":
-    # python build_hip.py [-f] [--tag NAME -DFOO=1 ...] [--only obj1,obj2.hip,...]
+    # python build_hip.py [-f] [--tag NAME -DFOO=1 --flag=-fno-slp-vectorize ...] [--only obj1,obj2.hip,...]
     argv = sys.argv[1:]
     tag = argv[argv.index("--tag") + 1] if "--tag" in argv else None
     only = argv[argv.index("--only") + 1].split(",") if "--only" in argv else None
-    print(build(force="-f" in argv, extra_flags=[a for a in argv if a.startswith("-D")], tag=tag, only=only))
+    print(build(force="-f" in argv, extra_flags=[a for a in argv if a.startswith("-D")] + [a[7:] for a in argv if a.startswith("--flag=")], tag=tag, only=only))

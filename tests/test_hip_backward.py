@@ -99,9 +99,22 @@ def test_encode_backward(hip):
     vol = G(sc["vol_static"]).requires_grad_(True)
     cam = {"w2cs": G(sc["w2cs"]), "intrinsics": G(sc["intrinsics"])}
     views = renderer._Views(vol.detach(), G(sc["imgs"]), cam)
-    x = za.EncodeFn.apply(ndc, vol, views, G(sc["rays_pts"])[0], G(sc["rays_dir"])[0], 0.3)
+    vol_g = za.VolumeCLFn.apply(vol, views)        # the volume enters in the kernels' layout, one node per volume
+    x = za.EncodeFn.apply(ndc, vol_g, views, G(sc["rays_pts"])[0], G(sc["rays_dir"])[0], 0.3)
     Wt = gc.zs.rng(6).standard_normal(tuple(x.shape)).astype(np.float32)
     (G(Wt) * x).sum().backward()
+    # the pair form (two frame indices, one [2R,S,C] batch, both halves scattering into one volume gradient)
+    ndc2, vol2 = ndc.detach().clone().requires_grad_(True), vol.detach().clone().requires_grad_(True)
+    ndc3 = (ndc.detach() * 0.9 + 0.03).requires_grad_(True)
+    xp = za.EncodePairFn.apply(ndc2, ndc3, za.VolumeCLFn.apply(vol2, views), views, G(sc["rays_pts"])[0],
+                               G(sc["rays_dir"])[0], 0.3, -0.2)
+    assert torch.equal(xp[:16], x.detach())
+    xb = views.encode(ndc3.detach(), G(sc["rays_pts"])[0], G(sc["rays_dir"])[0], -0.2)
+    assert torch.equal(xp[16:], xb)
+    (G(Wt) * xp[:16]).sum().backward(retain_graph=True)
+    gclose(ndc2.grad, ndc.grad.cpu().numpy(), "pair: g_ndc of the first half alone")
+    assert float(ndc3.grad.abs().max()) == 0.0
+    gclose(vol2.grad, vol.grad.cpu().numpy(), "pair: g_volume of the first half alone")
     # oracle
     t = lambda k: torch.from_numpy(sc[k])[0]
     ndc_o, vol_o = t("rays_ndc").clone().requires_grad_(True), t("vol_static").clone().requires_grad_(True)

@@ -313,3 +313,28 @@ def test_raw2outputs_uses_the_callers_dists(hip):
                                              G(bl["z"])[None], G(d2)[None])
     for n, a, b in zip(("rgb_map", "depth_map", "rgb_map_fg", "depth_map_fg", "weights_fg", "weights_dy"), gotb, wantb):
         close(a[0], b.numpy(), name="raw2outputs_blending(dists)/" + n)
+
+
+def test_raw2alpha_under_autograd(hip):
+    """raw2alpha (reference renderer.py:91-113) with a density that wants a gradient: weights through CompositeFn
+    (HIP backward), alpha through its defining ops - against the oracle's autograd on the same numbers."""
+    import zest_renderer as renderer
+    from oracle import zest_oracle as zo
+    comp = gc.composite_inputs(31, R=12, S=20, dead_ray=False)
+    z, d = torch.from_numpy(comp["z"]), torch.from_numpy(comp["rays_dir"])
+    dists = zo.sample_dists(z, torch.linalg.vector_norm(d, dim=-1, keepdim=True))
+    sig0 = torch.relu(torch.from_numpy(comp["raw"])[..., 3]) + 0.05
+    ga = gc.zs.rng(3).standard_normal(tuple(sig0.shape)).astype(np.float32)
+    gw = gc.zs.rng(4).standard_normal(tuple(sig0.shape)).astype(np.float32)
+    so = sig0.clone().requires_grad_(True)
+    alpha_o = 1.0 - torch.exp(-so * dists)
+    w_o = alpha_o * torch.cumprod(torch.cat([torch.ones_like(alpha_o[:, :1]), 1.0 - alpha_o + 1e-10], -1), -1)[:, :-1]
+    ((torch.from_numpy(ga) * alpha_o).sum() + (torch.from_numpy(gw) * w_o).sum()).backward()
+    sg = G(sig0.numpy()).requires_grad_(True)
+    a, w = renderer.raw2alpha(sg[None], G(dists.numpy())[None])
+    ((G(ga) * a[0]).sum() + (G(gw) * w[0]).sum()).backward()
+    close(a[0], alpha_o.detach().numpy(), name="raw2alpha/alpha (autograd)")
+    close(w[0], w_o.detach().numpy(), name="raw2alpha/weights (autograd)")
+    close(sg.grad, so.grad.numpy(), atol=1e-4, rtol=1e-3, name="raw2alpha/d sigma")
+    with pytest.raises(NotImplementedError, match="sample spacings"):
+        renderer.raw2alpha(sg[None], G(dists.numpy())[None].requires_grad_(True))

@@ -4,8 +4,8 @@ MLP).  Gradients exist exactly where the reference's training graph has them (SU
 
   EncodeFn     d/d(volume coordinates)  - through the positional encoding and the trilinear
                lookup (scene-flow displaced points, renderer.py:461,488) - and d/d(encoding
-               volume) (MVSNet trains through it); world points, images, cameras, directions
-               are data.
+               volume) (MVSNet trains through it; in the kernels' layout, VolumeCLFn converts once per step);
+               world points, images, cameras, directions are data.  EncodePairFn: the two neighbour frames in one batch.
   MlpFn        d/d(input point-encoding and feature columns) and d/d(every parameter).
   CompositeFn, BlendFn   d/d(raw predictions[, blend weight]); depth samples are data.
   Prob2dFn     compute_2d_prob: the weights are detached in the reference (renderer.py:31).
@@ -22,13 +22,31 @@ from torch.autograd import Function
 import zest_hip
 
 
+class VolumeCLFn(Function):
+    """The caller's encoding volume [1,8,D,H,W] -> the kernels' copy [H,W,D,8] (zest_utils' cached conversion) as ONE
+    autograd node per volume and step: every lookup of the step (the dynamic volume is read by three to five
+    passes) scatters into a channels-last gradient, autograd sums those, and the way back to the caller's layout is
+    paid once instead of per pass."""
+
+    @staticmethod
+    def forward(ctx, volume, views):
+        """views: renderer._Views (not a tensor: its cached channels-last copy is handed on as a new tensor object
+        on the same memory, which nobody writes)."""
+        ctx.shape = tuple(volume.shape)
+        return views.vol_cl.detach()
+
+    @staticmethod
+    def backward(ctx, g_cl):
+        return zest_hip.volume_from_cl(g_cl.contiguous()).view(ctx.shape), None
+
+
 class EncodeFn(Function):
     @staticmethod
-    def forward(ctx, ndc, volume, views, pts, dirs, t):
-        """ndc [R,S,3]; volume: the caller's [1,8,D,H,W] tensor or None; views: renderer._Views."""
+    def forward(ctx, ndc, vol_cl, views, pts, dirs, t):
+        """ndc [R,S,3]; vol_cl: VolumeCLFn's output when the volume wants a gradient, else None (the lookup reads
+        views.vol_cl either way); views: renderer._Views."""
         x = views.encode(ndc, pts, dirs, t)
         ctx.views, ctx.t = views, t
-        ctx.vol_shape = None if volume is None else tuple(volume.shape)
         ctx.save_for_backward(ndc)
         return x
 
@@ -36,11 +54,38 @@ class EncodeFn(Function):
     def backward(ctx, g_x):
         (ndc,) = ctx.saved_tensors
         v = ctx.views
-        want_vol = ctx.vol_shape is not None and ctx.needs_input_grad[1]
+        want_vol = v.vol_cl is not None and ctx.needs_input_grad[1]
         V = v.imgs_cl.shape[0] if v.imgs_cl is not None else 0
         g_ndc, g_vol_cl = zest_hip.encode_bwd(g_x.contiguous(), ndc, ctx.t, v.vol_cl, V, want_vol)
-        g_vol = zest_hip.volume_from_cl(g_vol_cl).view(ctx.vol_shape) if want_vol else None
-        return g_ndc, g_vol, None, None, None, None
+        return g_ndc, g_vol_cl, None, None, None, None
+
+
+class EncodePairFn(Function):
+    """Two encodes of the same rays at two frame indices (the neighbour frames t -+ 1 of the scene-flow chain,
+    reference renderer.py:460-497) into the halves of ONE [2R,S,C] batch, so the dynamic MLP runs forward and
+    backward once for both - one set of parameter gradients instead of two for autograd to add - and both halves
+    scatter into one volume gradient."""
+
+    @staticmethod
+    def forward(ctx, ndc_a, ndc_b, vol_cl, views, pts, dirs, t_a, t_b):
+        R, S = ndc_a.shape[:2]
+        x = ndc_a.new_empty(2 * R, S, views.c_in(True))
+        views.encode(ndc_a, pts, dirs, t_a, out=x[:R])
+        views.encode(ndc_b, pts, dirs, t_b, out=x[R:])
+        ctx.views, ctx.t = views, (t_a, t_b)
+        ctx.save_for_backward(ndc_a, ndc_b)
+        return x
+
+    @staticmethod
+    def backward(ctx, g_x):
+        ndc_a, ndc_b = ctx.saved_tensors
+        v, R = ctx.views, ndc_a.shape[0]
+        want_vol = v.vol_cl is not None and ctx.needs_input_grad[2]
+        V = v.imgs_cl.shape[0] if v.imgs_cl is not None else 0
+        g_x = g_x.contiguous()
+        g_a, g_vol_cl = zest_hip.encode_bwd(g_x[:R], ndc_a, ctx.t[0], v.vol_cl, V, want_vol)
+        g_b, g_vol_cl = zest_hip.encode_bwd(g_x[R:], ndc_b, ctx.t[1], v.vol_cl, V, want_vol, g_vol=g_vol_cl)
+        return g_a, g_b, g_vol_cl, None, None, None, None, None
 
 
 class MlpFn(Function):
@@ -75,17 +120,23 @@ class MlpFn(Function):
 class MlpFn16(Function):
     """bf16 training path: forward and backward entirely on the hand-written MFMA kernels
     (zest_mlp_train16_*): engine forward with activation stash; data / modulation / weight-gradient
-    kernels.  fp32 parameters in, fp32 gradients out; 'v0' nets."""
+    kernels.  fp32 parameters in, fp32 gradients out; 'v0' nets.  `shared`: a dict the calls of one net within one
+    rendering() share - the packed forward and transposed backward weight streams are built once per step, not
+    once per pass (the dynamic net runs two to three passes)."""
 
     @staticmethod
-    def forward(ctx, x, desc, slots, *params):
+    def forward(ctx, x, desc, slots, shared, *params):
         table = [None] * (2 * zest_hip.P_COUNT)
         for i, s in enumerate(slots):
             table[2 * s], table[2 * s + 1] = params[2 * i].detach(), params[2 * i + 1].detach()
         lead = x.shape[:-1]
         x2 = x.detach().reshape(-1, x.shape[-1]).contiguous()
-        out, stash = zest_hip.mlp_train16_fwd(desc, zest_hip.mlp_pack(desc, zest_hip.PREC_BF16, table), x2)
-        ctx.desc, ctx.slots, ctx.lead = desc, slots, lead
+        if shared is None:
+            shared = {}
+        if "fwd" not in shared:
+            shared["fwd"] = zest_hip.mlp_pack(desc, zest_hip.PREC_BF16, table)
+        out, stash = zest_hip.mlp_train16_fwd(desc, shared["fwd"], x2)
+        ctx.desc, ctx.slots, ctx.lead, ctx.shared = desc, slots, lead, shared
         ctx.save_for_backward(x2, stash, out, *params)
         return out.view(*lead, desc.out_ch)
 
@@ -95,12 +146,15 @@ class MlpFn16(Function):
         table = [None] * (2 * zest_hip.P_COUNT)
         for i, s in enumerate(ctx.slots):
             table[2 * s], table[2 * s + 1] = params[2 * i].detach(), params[2 * i + 1].detach()
-        g_x, grads, _ = zest_hip.mlp_train16_bwd(ctx.desc, zest_hip.mlp_train16_pack_bwd(ctx.desc, table), table, x2,
-                                                 stash, out, g_out.reshape(-1, ctx.desc.out_ch).contiguous())
+        if "bwd" not in ctx.shared:
+            ctx.shared["bwd"] = zest_hip.mlp_train16_pack_bwd(ctx.desc, table)
+        g_x, grads, ctx.shared["work"] = zest_hip.mlp_train16_bwd(
+            ctx.desc, ctx.shared["bwd"], table, x2, stash, out, g_out.reshape(-1, ctx.desc.out_ch).contiguous(),
+            work=ctx.shared.get("work"))
         gp = []
         for s in ctx.slots:
             gp += [grads[2 * s], grads[2 * s + 1]]
-        return (g_x.view(*ctx.lead, -1) if ctx.needs_input_grad[0] else None, None, None, *gp)
+        return (g_x.view(*ctx.lead, -1) if ctx.needs_input_grad[0] else None, None, None, None, *gp)
 
 
 class CompositeFn(Function):
@@ -175,6 +229,19 @@ class SplitLastFn(Function):
         return (torch.cat(parts, -1),) + (None,) * len(ctx.sizes)
 
 
+class SplitRowsFn(Function):
+    """x [n R, ...] -> n blocks of R rows; backward is one concatenation (autograd's own slice backward fills and
+    copies a full-size tensor per block)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.chunk(n, 0))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        return torch.cat(grads, 0), None
+
+
 def split_last(raw, sizes):
     """Column groups of raw's last dimension: under autograd through SplitLastFn, otherwise plain views."""
     if torch.is_grad_enabled() and raw.requires_grad:
@@ -182,11 +249,11 @@ def split_last(raw, sizes):
     return raw.split(sizes, -1)
 
 
-def mlp_apply(net, x, time_codes=None, bf16=False):
+def mlp_apply(net, x, time_codes=None, bf16=False, shared=None):
     """Training forward of a zest networks.MVSNeRF on x [..., C_in] with autograd.  time_codes: the
     frame's latent code for a net with time-code channels (folded into layer 0 / 5 biases with
     differentiable torch ops: gradients reach the code and the full-width weights).  bf16: the fast
-    training mode (MlpFn16, 'v0' nets); otherwise the fp32 parity path (MlpFn)."""
+    training mode (MlpFn16, 'v0' nets); otherwise the fp32 parity path (MlpFn).  shared: see MlpFn16."""
     mod = net.nerf
     desc = mod._desc()
     named = mod.effective_parameters(time_codes)
@@ -200,7 +267,7 @@ def mlp_apply(net, x, time_codes=None, bf16=False):
         slots.append(slot)
         params += [named[name + ".weight"], named[name + ".bias"]]
     if bf16 and desc.net_type == 0 and desc.is_default_shape:      # the MFMA training kernels' shape
-        return MlpFn16.apply(x, desc, tuple(slots), *params)
+        return MlpFn16.apply(x, desc, tuple(slots), shared, *params)
     return MlpFn.apply(x, desc, tuple(slots), *params)
 
 

@@ -412,8 +412,9 @@ def color_lookup(imgs_cl, w2cs, intrinsics, pts):
     return out
 
 
-def encode(ndc, pts, rays_dir, t=None, vol_cl=None, imgs_cl=None, w2cs=None, intrinsics=None):
-    """ndc, pts [R,S,3]; rays_dir [R,3] -> x [R,S,C_in] (reference prepare_pts layout)."""
+def encode(ndc, pts, rays_dir, t=None, vol_cl=None, imgs_cl=None, w2cs=None, intrinsics=None, out=None):
+    """ndc, pts [R,S,3]; rays_dir [R,3] -> x [R,S,C_in] (reference prepare_pts layout); out: a contiguous
+    [R,S,C_in] fp32 tensor to write into (e.g. half of a larger batch) instead of a new one."""
     ndc = _dev(ndc, "ndc", (None, None, 3))
     R, S, _ = ndc.shape
     pts, rays_dir = _dev(pts, "pts", (R, S, 3)), _dev(rays_dir, "rays_dir", (R, 3))
@@ -429,7 +430,7 @@ def encode(ndc, pts, rays_dir, t=None, vol_cl=None, imgs_cl=None, w2cs=None, int
     if w2cs is not None and w2cs.shape[-2:] != (4, 4):
         raise RuntimeError("zest_hip: w2cs has shape %s, expected (..., 4, 4)" % (tuple(w2cs.shape),))
     c_in = (4 if has_t else 3) * 21 + (8 + 4 * V if vol_cl is not None else 0) + 27
-    x = torch.empty(R, S, c_in, device=ndc.device, dtype=torch.float32)
+    x = torch.empty(R, S, c_in, device=ndc.device, dtype=torch.float32) if out is None else _dev(out, "out", (R, S, c_in))
     _check(lib().zest_encode_fwd(_ptr(ndc), _ptr(pts), _ptr(rays_dir), R, S, int(has_t),
                                  float(t) if has_t else 0.0, _ptr(vol_cl), D, Hv, Wv, _ptr(imgs_cl),
                                  V, H, W, _ptr(w2cs), _ptr(intrinsics), _ptr(x), _stream(ndc)),
@@ -513,19 +514,20 @@ def composite_blend_bwd(raw_dy, raw_st, blend, z, rays_dir, noise, noise_std, g_
 
 
 # ------------------------------------------------------------------- training path (backward)
-def encode_bwd(g_x, ndc, t, vol_cl, V, want_vol_grad):
-    """-> g_ndc [R,S,3], g_vol_cl [H,W,D,8] or None."""
+def encode_bwd(g_x, ndc, t, vol_cl, V, want_vol_grad, g_vol=None):
+    """-> g_ndc [R,S,3], g_vol_cl [H,W,D,8] or None.  g_vol: an existing volume gradient to add into (the kernel
+    scatter-adds) instead of a fresh zero-filled one."""
     ndc = _dev(ndc, "ndc", (None, None, 3))
     R, S, _ = ndc.shape
     c_in = (4 if t is not None else 3) * 21 + (8 + 4 * int(V) if vol_cl is not None else 0) + 27
     g_x = _dev(g_x, "g_x", (R, S, c_in))
     D = Hv = Wv = 0
-    g_vol = None
+    add_to, g_vol = g_vol, None
     if vol_cl is not None:
         vol_cl = _dev(vol_cl, "vol_cl", (None, None, None, 8))
         Hv, Wv, D, _ = vol_cl.shape
         if want_vol_grad:
-            g_vol = torch.zeros_like(vol_cl)
+            g_vol = torch.zeros_like(vol_cl) if add_to is None else _dev(add_to, "g_vol", tuple(vol_cl.shape))
     g_ndc = torch.empty_like(ndc)
     _check(lib().zest_encode_bwd(_ptr(g_x), _ptr(ndc), R, S, int(t is not None), float(t) if t is not None else 0.0,
                                  _ptr(vol_cl), D, Hv, Wv, int(V), _ptr(g_ndc), _ptr(g_vol), _stream(ndc)),
@@ -663,7 +665,13 @@ def mlp_train16_bwd(desc, packed_bwd, params, x, stash, out, g_out, stages=7, wo
     for p, n in zip(keep, sizes):
         grads.append(flat[off:off + p.numel()].view(p.shape) if p is not None else None)
         off += n
-    g_x = torch.zeros_like(x)
+    # the finishing kernel writes every point and feature column of every row; the direction columns receive no
+    # gradient (data) and are the only ones that need the zero
+    g_x = torch.empty_like(x)
+    if stages & 2:
+        g_x[..., desc.in_ch_pts + (desc.in_ch_feat if desc.use_feat else 0):].zero_()
+    else:
+        g_x.zero_()
     _check(lib().zest_mlp_train16_bwd(C.byref(desc), _ptr(packed_bwd), _ptr_table(keep), _ptr(x), M, _ptr(stash), _ptr(out),
                                       _ptr(g_out), _ptr(work), _ptr(g_x), _ptr_table(grads), int(stages), _stream(x)),
            "zest_mlp_train16_bwd")

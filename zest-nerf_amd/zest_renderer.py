@@ -33,13 +33,6 @@ def _draw_noise(shape, device):
     return torch.randn(shape, device=device)
 
 
-def _no_grad_only(*tensors):
-    if torch.is_grad_enabled() and any(t is not None and torch.is_tensor(t) and t.requires_grad
-                                       for t in tensors):
-        raise NotImplementedError("zest renderer: backward kernels are not built yet "
-                                  "(SURVEY.md 8(f) next-2); call under torch.no_grad()")
-
-
 # ------------------------------------------------------------------ reference helper surface
 def compute_2d_prob(weights_p_mix, raw_prob_ref2p):
     """sum_s w * (1 - prob)  (reference renderer.py:22-32)."""
@@ -61,12 +54,24 @@ def depth2dist(z_vals, cos_angle):
 def raw2alpha(sigma, dist):
     """alpha = 1 - exp(-sigma*dist), weights = alpha * exclusive-prod(1 - alpha + 1e-10)
     (reference renderer.py:91-113), on the compositing kernel with the caller's spacings; sigma < 0
-    is clamped to 0, which every reference caller has already done."""
-    _no_grad_only(sigma, dist)
+    is clamped to 0, which every reference caller has already done.  Under autograd the weights come from
+    CompositeFn (HIP forward and backward) and alpha from the two elementwise ops that define it; the spacings
+    are data, as in every call site of the reference."""
     lead, S = sigma.shape[:-1], sigma.shape[-1]
     d = dist.reshape(-1, S).float()
+    sg = sigma.reshape(-1, S).float()
+    if torch.is_grad_enabled() and dist.requires_grad:
+        raise NotImplementedError("zest raw2alpha: a gradient with respect to the sample spacings is not provided "
+                                  "(no caller of the reference differentiates them: renderer.py:74-89 builds them "
+                                  "from the depth samples)")
+    if torch.is_grad_enabled() and sigma.requires_grad:
+        import zest_autograd as za
+        raw = torch.cat([torch.zeros(sg.shape[0], S, 3, device=sg.device), sg[..., None]], -1)
+        w = za.CompositeFn.apply(raw, torch.zeros_like(d), d.contiguous(), None, 0.0, False, True)[3]
+        a = 1.0 - torch.exp(-torch.relu(sg) * d)
+        return a.view(*lead, S), w.view(*lead, S)
     raw = torch.zeros(d.shape[0], S, 4, device=d.device)
-    raw[..., 3] = sigma.reshape(-1, S)
+    raw[..., 3] = sg
     _, _, _, w, _, a = zest_hip.composite(raw, torch.zeros_like(d), None, dists=d)
     return a.view(*lead, S), w.view(*lead, S)
 
@@ -123,8 +128,12 @@ class _Views:
             self.vol_cl = volume_channels_last(volume)
             self.imgs_cl = images_channels_last(imgs)
 
-    def encode(self, ndc, pts, rays_dir, t=None):
-        return zest_hip.encode(ndc, pts, rays_dir, t, self.vol_cl, self.imgs_cl, self.w2cs, self.intr)
+    def encode(self, ndc, pts, rays_dir, t=None, out=None):
+        return zest_hip.encode(ndc, pts, rays_dir, t, self.vol_cl, self.imgs_cl, self.w2cs, self.intr, out=out)
+
+    def c_in(self, has_t):
+        """input width of the MLP these views feed: PE(xyz[t]) + 8 + 4V features + PE(direction)"""
+        return (4 if has_t else 3) * 21 + (8 + 4 * self.imgs_cl.shape[0] if self.vol_cl is not None else 0) + 27
 
 
 def _check_embedders(embedding_pts, embedding_dir, in_channels):
@@ -227,15 +236,23 @@ def rendering(args, rays_pts, rays_ndc, depth_candidates, rays_dir,
 
     train16 = prec in (zest_hip.PREC_BF16, zest_hip.PREC_F16)       # --precision 16: bf16 MFMA training kernels
 
+    shared = {}                 # per net: what its passes of this call share (packed weight streams, work buffer)
+
     def mlp(net, x, tc=None):
         if train:
-            return za.mlp_apply(net, x, tc, bf16=train16)
+            return za.mlp_apply(net, x, tc, bf16=train16, shared=shared.setdefault(id(net), {}))
         p = net.nerf.engine_precision(mlp_prec)
         return zest_hip.mlp_fwd(net.desc(), p, net.packed(p, tc), x)
 
+    def vol_node(views, volume):
+        # the volume's channels-last copy as an autograd node (one per volume and call) when the volume trains
+        if getattr(views, "vol_g", None) is None and volume is not None and torch.is_tensor(volume) and volume.requires_grad:
+            views.vol_g = za.VolumeCLFn.apply(volume, views)
+        return getattr(views, "vol_g", None)
+
     def encode(views, volume, ndc3, t=None):
         if train:
-            return za.EncodeFn.apply(ndc3, volume, views, pts, dirs, None if t is None else float(t))
+            return za.EncodeFn.apply(ndc3, vol_node(views, volume), views, pts, dirs, None if t is None else float(t))
         return views.encode(ndc3, pts, dirs, t)
 
     def composite(raw4, nz, std, white):
@@ -318,11 +335,19 @@ def rendering(args, rays_pts, rays_ndc, depth_candidates, rays_dir,
             return za.Prob2dFn.apply(w.detach(), p.contiguous())
         return zest_hip.weighted_complement_sum(w, p)
 
-    ndc_prev = ndc + sf_prev
-    prev4, prev_4_7, prev_7_10 = parts(dyn_pass(ndc_prev, ref_frame_idx - step))
+    ndc_prev, ndc_post = ndc + sf_prev, ndc + sf_post
+    if train:
+        # the two neighbour frames as ONE batch of 2R rays through the dynamic net (the reference runs them one after
+        # the other, renderer.py:460-505; rays are independent, so the rows are the same): one forward, one backward,
+        # one set of parameter gradients for autograd to add instead of two
+        x_nb = za.EncodePairFn.apply(ndc_prev, ndc_post, vol_node(vd, volume_feature_dynamic), vd, pts, dirs,
+                                     float(ref_frame_idx - step), float(ref_frame_idx + step))
+        raw_prev, raw_post = za.SplitRowsFn.apply(mlp(net_d, x_nb), 2)
+    else:
+        raw_prev, raw_post = dyn_pass(ndc_prev, ref_frame_idx - step), dyn_pass(ndc_post, ref_frame_idx + step)
+    prev4, prev_4_7, prev_7_10 = parts(raw_prev)
     rgb_prev, w_prev = nb_render(prev4)
-    ndc_post = ndc + sf_post
-    post4, post_4_7, post_7_10 = parts(dyn_pass(ndc_post, ref_frame_idx + step))
+    post4, post_4_7, post_7_10 = parts(raw_post)
     rgb_post, w_post = nb_render(post4)
     ret.update({'raw_pts_prev': ndc_prev[None], 'raw_sf_prev2ref': prev_7_10[None],
                 'rgb_map_prev_dy': rgb_prev[None], 'raw_pts_post': ndc_post[None],

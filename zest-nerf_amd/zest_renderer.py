@@ -336,10 +336,11 @@ def rendering(args, rays_pts, rays_ndc, depth_candidates, rays_dir,
         return zest_hip.weighted_complement_sum(w, p)
 
     ndc_prev, ndc_post = ndc + sf_prev, ndc + sf_post
-    if train:
+    if train and train16:
         # the two neighbour frames as ONE batch of 2R rays through the dynamic net (the reference runs them one after
         # the other, renderer.py:460-505; rays are independent, so the rows are the same): one forward, one backward,
-        # one set of parameter gradients for autograd to add instead of two
+        # one set of parameter gradients for autograd to add instead of two.  bf16 kernels only: the fp32 path's
+        # rocBLAS GEMMs run 20 % slower per sample on the doubled batch (49 against 41 ms per step)
         x_nb = za.EncodePairFn.apply(ndc_prev, ndc_post, vol_node(vd, volume_feature_dynamic), vd, pts, dirs,
                                      float(ref_frame_idx - step), float(ref_frame_idx + step))
         raw_prev, raw_post = za.SplitRowsFn.apply(mlp(net_d, x_nb), 2)

@@ -76,7 +76,7 @@ def test_train16_forward_and_backward_match_the_oracle(hip, case, M):
         names[slot] = name
     names[13] = {zh.HEAD_BLEND: "w_linear", zh.HEAD_DYNAMIC: "sf_linear"}.get(desc.head)
     names[14] = "prob_linear" if desc.head == zh.HEAD_DYNAMIC else None
-    checked = 0
+    checked, worst = 0, 0.0
     for slot in range(zh.P_COUNT):
         if tab[2 * slot] is None or names.get(slot) is None:
             continue
@@ -87,8 +87,9 @@ def test_train16_forward_and_backward_match_the_oracle(hip, case, M):
             e = rel(got, want)
             # (a single sample: every tensor is one outer product of bf16-rounded factors)
             assert e < (5e-2 if M > 1 else 8e-2), "%s.%s: relative L2 error %.3g" % (names[slot], kind, e)
-            checked += 1
+            checked, worst = checked + 1, max(worst, e)
     assert checked >= 24
+    print("train16 %s M=%d: worst parameter-gradient tensor %.4f relative L2 (bound %.2f)" % (case, M, worst, 5e-2 if M > 1 else 8e-2))
 
 
 @pytest.mark.parametrize("case", ["grad_static", "grad_zest_5f"])
@@ -158,3 +159,93 @@ def test_rendering_trains_in_bf16_mode(hip, case):
             assert cos > 0.6, "%s: cosine %.4f, norm ratio %.3f" % (k, cos, na / nb)
         else:       # dynamic net / volume: dominated by the chained passes (displaced points through sin(512 x)),
             assert na > 0       # where a 1e-3 operand perturbation of these random-weight nets decorrelates the terms
+
+
+def _hip_render_grads(case, precision):
+    """Train-mode rendering() of a gradient case on the GPU -> (loss, {leaf name: gradient ndarray}) with the leaf
+    naming of oracle_run.oracle_render_grads."""
+    import zest_networks as networks
+    import zest_renderer as renderer
+    from types import SimpleNamespace
+    from test_hip_render import build_nets
+    c, sc = gc.CASES[case], gc.build(case)
+    sf = sc["scene_flow"]
+    ns, nd = build_nets(sc)
+    vol_s = G(sc["vol_static"]).requires_grad_(True)
+    vol_d = G(sc["vol_dynamic"]).requires_grad_(True) if sf else None
+    args = SimpleNamespace(netchunk=1024, feat_dim=sc["feat_dim"], feat_dim_dy=24, img_downscale=1.0,
+                           use_color_volume=False, net_type="v0", precision=precision)
+    cam = {"w2cs": G(sc["w2cs"]), "intrinsics": G(sc["intrinsics"])}
+    nb_cam = {"w2cs": G(sc["nb_w2cs"]), "intrinsics": G(sc["nb_intrinsics"])} if sf else None
+    ret = renderer.rendering(
+        args, G(sc["rays_pts"]), G(sc["rays_ndc"]), G(sc["depth_candidates"]), G(sc["rays_dir"]),
+        volume_feature_static=vol_s, volume_feature_dynamic=vol_d, imgs=G(sc["imgs"]),
+        neighbour_frames=G(sc["nb_imgs"]) if sf else None, im_cam_mat=cam, nb_cam_mat=nb_cam, network_fn=ns,
+        network_fn_dy=nd, embedding_pts=networks.Embedding(3, 10), embedding_xyzt=networks.Embedding(4, 10),
+        embedding_dir=networks.Embedding(3, 4), chain_bwd=c.get("chain_bwd", False),
+        chain_5frames=c.get("chain_5frames", False), ref_frame_idx=gc.REF_FRAME_IDX, num_frames=gc.NUM_FRAMES,
+        white_bkgd=c.get("white_bkgd", False), scene_flow=sf, val=False)
+    W = gc.loss_weights(c["seed"], {k: tuple(v.shape[1:]) for k, v in ret.items() if v is not None})
+    loss = sum((G(W[k]) * ret[k][0]).sum() for k in W)
+    loss.backward()
+    got = {"vol_static": vol_s.grad[0]}
+    if sf:
+        got["vol_dynamic"] = vol_d.grad[0]
+    for tag, net in (("static", ns), ("dynamic", nd)):
+        if net is not None:
+            got.update({"%s.%s" % (tag, k): p.grad for k, p in net.named_parameters() if p.grad is not None})
+    return float(loss.detach()), {k: v.double().cpu().numpy() for k, v in got.items()}
+
+
+def _agg(grads, prefix):
+    return np.concatenate([v.ravel() for k, v in sorted(grads.items()) if k.startswith(prefix)])
+
+
+@pytest.mark.parametrize("case", ["grad_static", "grad_zest_5f"])
+def test_bf16_training_gradients_against_the_bf16_operand_oracle(hip, case):
+    """End to end through the autograd wiring (MlpFn16, EncodePairFn, SplitLastFn / SplitRowsFn, BlendFn, the chained
+    scene-flow passes): --precision 16 rendering() against the ORACLE's whole rendering() differentiated with every
+    GEMM operand rounded to bf16 (_Bf16Operands: the same network the kernels evaluate, so the ReLU masks agree up to
+    the few units the two summation orders round differently).  Bounds on the gradient of each net / volume taken as
+    one vector (relative L2 error; cosine): 2 % for the static scene, 5 % for the static net and volume of the ZeST
+    scene, 25 % at cosine > 0.97 for the dynamic net and volume - whose passes at t +- 1, t +- 2 see points displaced by
+    the net's own output, through sin(512 x)."""
+    with _Bf16Operands():
+        want_loss, want = orun.oracle_render_grads(case)
+    got_loss, got = _hip_render_grads(case, 16)
+    assert sorted(got) == sorted(want)
+    assert abs(got_loss - want_loss) <= 2e-2 * max(1.0, abs(want_loss)), (got_loss, want_loss)
+    groups = ["static.", "vol_static"] + (["dynamic.", "vol_dynamic"] if case != "grad_static" else [])
+    report = {}
+    for g in groups:
+        a, b = _agg(got, g), _agg(want, g)
+        cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+        report[g] = (rel(a, b), cos, float(np.linalg.norm(a) / (np.linalg.norm(b) + 1e-30)))
+    print("bf16 end-to-end gradients vs the bf16-operand oracle (rel L2, cosine, norm ratio):", case, report)
+    # measured (MI355X): static scene 0.2 - 0.4 % relative L2; ZeST 5-frame: static net / volume 1.0 - 1.3 %, dynamic
+    # net / volume 9 - 10 % at cosine 0.995 - 0.997
+    tight = {"grad_static": 0.02, "grad_zest_5f": 0.05}[case]
+    for g in ("static.", "vol_static"):
+        assert report[g][0] < tight and report[g][1] > 0.998, (g, report[g])
+    for g in groups[2:]:
+        assert report[g][0] < 0.25 and report[g][1] > 0.97 and 0.8 < report[g][2] < 1.25, (g, report[g])
+
+
+def test_split_fns_against_plain_slicing(hip):
+    """SplitLastFn / SplitRowsFn (one concatenation in backward) against torch's own slicing, with column groups
+    that receive no gradient at all."""
+    import zest_autograd as za
+    x = torch.randn(6, 5, 12, device="cuda:0")
+    a, b = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    pa = za.SplitLastFn.apply(a, 4, 3, 3, 2)
+    pb = b.split((4, 3, 3, 2), -1)
+    wa, wc = torch.randn_like(pa[0]), torch.randn_like(pa[2])
+    ((pa[0] * wa).sum() + (pa[2] * wc).square().sum()).backward()          # groups 1 and 3 unused
+    ((pb[0] * wa).sum() + (pb[2] * wc).square().sum()).backward()
+    assert torch.equal(a.grad, b.grad)
+    a2, b2 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ra, rb = za.SplitRowsFn.apply(a2, 2), b2.chunk(2, 0)
+    w0, w1 = torch.randn_like(ra[0]), torch.randn_like(ra[1])
+    ((ra[0] * w0).sum() + (ra[1] * w1).sum()).backward()
+    ((rb[0] * w0).sum() + (rb[1] * w1).sum()).backward()
+    assert torch.equal(a2.grad, b2.grad)

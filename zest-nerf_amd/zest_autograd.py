@@ -268,6 +268,11 @@ def mlp_apply(net, x, time_codes=None, bf16=False, shared=None):
         params += [named[name + ".weight"], named[name + ".bias"]]
     if bf16 and desc.net_type == 0 and desc.is_default_shape:      # the MFMA training kernels' shape
         return MlpFn16.apply(x, desc, tuple(slots), shared, *params)
+    if bf16:
+        import warnings
+        warnings.warn("zest: --precision 16 training of a %s net takes the fp32 training path (rocBLAS sgemm): the "
+                      "bf16 MFMA training kernels cover 'v0' nets of depth 8 / width 256 / skips [4]"
+                      % ("'v2'" if desc.net_type else "D=%d W=%d" % (desc.D, desc.W)), stacklevel=2)
     return MlpFn.apply(x, desc, tuple(slots), *params)
 
 

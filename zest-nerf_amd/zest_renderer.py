@@ -235,6 +235,11 @@ def rendering(args, rays_pts, rays_ndc, depth_candidates, rays_dir,
     mlp_prec = inference_precision(prec, args)
 
     train16 = prec in (zest_hip.PREC_BF16, zest_hip.PREC_F16)       # --precision 16: bf16 MFMA training kernels
+    if train and prec == zest_hip.PREC_F16:
+        import warnings
+        warnings.warn("zest: zest_dtype16='f16' selects fp16 operands for inference only; under autograd --precision 16 "
+                      "trains on the bf16 MFMA kernels (a gradient wants bf16's exponent range), so this run trains in "
+                      "bf16 and evaluates in fp16", stacklevel=2)
 
     shared = {}                 # per net: what its passes of this call share (packed weight streams, work buffer)
 

@@ -1,0 +1,138 @@
+"""GPU: coarse -> fine rendering (zest_renderer.render_hierarchical), a BUILD EXTENSION with no counterpart in the
+reference (--N_importance is parsed, opt.py:161, and never used; there is no sample_pdf): PARITY UNPINNED for the
+sampler.  What is pinned: the second pass is an ordinary rendering() call, so its maps are checked against the oracle
+evaluated on the very samples the sampler chose; the sampler and the merge are checked by properties."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+import oracle_run
+from test_hip_ops import G, close, ATOL, RTOL
+from test_hip_render import build_nets
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(case="render_static_mvs", R=None):
+    import zest_networks as networks
+    sc, c = gc.build(case), gc.CASES[case]
+    nets = build_nets(sc)
+    cam = {"w2cs": G(sc["w2cs"]), "intrinsics": G(sc["intrinsics"])}
+    kw = dict(volume_feature_static=G(sc["vol_static"]), imgs=G(sc["imgs"]), im_cam_mat=cam, network_fn=nets[0],
+              embedding_pts=networks.Embedding(3, 10), embedding_xyzt=networks.Embedding(4, 10),
+              embedding_dir=networks.Embedding(3, 4), white_bkgd=c.get("white_bkgd", False))
+    if sc["scene_flow"]:
+        kw.update(volume_feature_dynamic=G(sc["vol_dynamic"]), neighbour_frames=G(sc["nb_imgs"]),
+                  nb_cam_mat={"w2cs": G(sc["nb_w2cs"]), "intrinsics": G(sc["nb_intrinsics"])}, network_fn_dy=nets[1],
+                  ref_frame_idx=gc.REF_FRAME_IDX, num_frames=gc.NUM_FRAMES, scene_flow=True, val=True)
+    rays = [G(sc[k]) for k in ("rays_pts", "rays_ndc", "depth_candidates", "rays_dir")]
+    H, W, pad = sc["H"], sc["W"], sc["pad"]
+
+    def ndc_of(p):          # the synthetic scenes' own world -> volume map (zest_synth.project_ndc: view 0, near 2, far 6)
+        import zest_utils as utils
+        inv = torch.tensor([W - 1.0, H - 1.0])
+        return utils.get_ndc_coordinate(cam["w2cs"][:, 0], cam["intrinsics"][:, 0], p, inv, near=2.0, far=6.0, pad=pad)
+    return sc, c, kw, rays, ndc_of
+
+
+def _args(sc, precision=32, maps_only=False):
+    return SimpleNamespace(netchunk=4096, feat_dim=sc["feat_dim"], feat_dim_dy=24, img_downscale=1.0,
+                           use_color_volume=False, net_type="v0", precision=precision, zest_maps_only=maps_only)
+
+
+def test_mapper_and_merge(hip):
+    """The test's world -> volume map reproduces the scene's own coordinates (so new samples land where the ray
+    sampler would have put them), and merge_samples returns ascending depths and points on the rays."""
+    import zest_renderer as renderer
+    sc, c, kw, rays, ndc_of = _setup()
+    assert (ndc_of(rays[0]) - rays[1]).abs().max().item() < 2e-5
+    z_new = rays[2][:, :, 3:7] + 0.013
+    z_all, pts_all = renderer.merge_samples(rays[0], rays[2], rays[3], z_new)
+    S = rays[2].shape[-1]
+    assert z_all.shape[-1] == S + 4 and bool((z_all[..., 1:] >= z_all[..., :-1]).all())
+    o = rays[0][0, :, 0] - rays[2][0, :, :1] * rays[3][0]
+    want = o[:, None] + z_all[0, ..., None] * rays[3][0][:, None]
+    assert torch.allclose(pts_all[0], want, atol=1e-6)
+
+
+@pytest.mark.parametrize("case", ["render_static_mvs", "render_zest_val"])
+def test_fine_pass_matches_the_oracle_on_the_chosen_samples(hip, case):
+    """render_hierarchical in fp32 mode: N_importance new depths per ray, inside the coarse range and ascending after
+    the merge; the returned maps equal the ORACLE's render of the merged samples (1e-4 + 1e-3 |ref|), i.e. everything
+    after the sampler is the pinned path; the coarse maps are the single-pass render."""
+    import zest_renderer as renderer
+    sc, c, kw, rays, ndc_of = _setup(case)
+    S, N = rays[2].shape[-1], 8
+    with torch.no_grad():
+        out = renderer.render_hierarchical(_args(sc), *rays, N, ndc_of, det=True, **kw)
+        single = renderer.rendering(_args(sc), *rays, **kw)
+    z_all = out["z_vals"]
+    assert z_all.shape == (1, rays[2].shape[1], S + N)
+    assert bool((z_all[..., 1:] >= z_all[..., :-1]).all())
+    assert z_all.min() >= rays[2].min() - 1e-6 and z_all.max() <= rays[2].max() + 1e-6
+    key = "rgb_map_ref" if sc["scene_flow"] else "rgb_map"
+    assert torch.equal(out["rgb_map_coarse"], single[key])
+    # oracle on the merged samples
+    o = rays[0][0, :, 0] - rays[2][0, :, :1] * rays[3][0]
+    pts = (o[:, None] + z_all[0, ..., None] * rays[3][0][:, None])[None]
+    sc2 = dict(sc, rays_pts=pts.cpu().numpy(), rays_ndc=ndc_of(pts).cpu().numpy(),
+               depth_candidates=z_all.cpu().numpy())
+    if sc["scene_flow"]:
+        sc2["noise_static"] = np.zeros((z_all.shape[1], S + N), np.float32)
+        sc2["noise_blend"] = sc2["noise_static"]
+    want = oracle_run.oracle_render(dict(c, val=True) if sc["scene_flow"] else c, sc2, explicit=False)
+    for k in (("rgb_map", "depth_map") + (("rgb_map_ref", "depth_map_ref") if sc["scene_flow"] else ())):
+        close(out[k][0], want[k].numpy(), atol=ATOL, rtol=RTOL, name="hierarchical/%s/%s" % (case, k))
+
+
+def test_duplicated_samples_change_nothing_and_mass_follows_the_weights(hip, monkeypatch):
+    """(1) If the sampler hands back depths the coarse pass already has, the fine render equals the single-pass one: a
+    repeated depth is a zero-length interval (alpha 0), whatever the net says there.  (2) With the real sampler most
+    of the new depths fall where the coarse weights are: in bins that hold 80 % of the weight... at least 70 % of them."""
+    import zest_renderer as renderer
+    import zest_utils as utils
+    sc, c, kw, rays, ndc_of = _setup()
+    args = _args(sc)
+    with torch.no_grad():
+        single = renderer.rendering(args, *rays, **kw)
+    monkeypatch.setattr(utils, "sample_pdf", lambda bins, w, n, det=False: rays[2][0][:, 2:2 + n].clone())
+    with torch.no_grad():
+        dup = renderer.render_hierarchical(args, *rays, 6, ndc_of, **kw)
+    for k in ("rgb_map", "depth_map"):
+        close(dup[k][0], single[k][0].cpu().numpy(), atol=ATOL, rtol=RTOL, name="duplicates/" + k)
+    monkeypatch.undo()
+    with torch.no_grad():
+        out = renderer.render_hierarchical(args, *rays, 32, ndc_of, det=True, **kw)
+    z, w = rays[2][0], single["weights"][0]
+    mids = 0.5 * (z[:, 1:] + z[:, :-1])
+    wi = w[:, 1:-1]
+    S = z.shape[1]
+    hits = tot = 0
+    zs = out["z_vals"][0]
+    for r in range(z.shape[0]):
+        if float(wi[r].sum()) < 1e-3:
+            continue
+        order = torch.argsort(wi[r], descending=True)
+        csum = torch.cumsum(wi[r][order], 0) / wi[r].sum()
+        heavy = set(order[: int((csum < 0.8).sum()) + 1].tolist())           # bins holding 80 % of the weight
+        # the new depths of the ray: those of the merged set that are not coarse depths
+        new = [v for v in zs[r].tolist() if min(abs(v - c0) for c0 in z[r].tolist()) > 0]
+        for v in new:
+            b = int(torch.searchsorted(mids[r], torch.tensor(v, device=mids.device)).item()) - 1
+            tot += 1
+            hits += int(b in heavy)
+    assert tot > 0 and hits / tot > 0.7, (hits, tot)
+
+
+def test_fused_fine_pass(hip):
+    """The fine pass through the fused single-launch kernel (bf16) against the same call per operator."""
+    import zest_renderer as renderer
+    sc, c, kw, rays, ndc_of = _setup()
+    with torch.no_grad():
+        a = renderer.render_hierarchical(_args(sc, 16, True), *rays, 16, ndc_of, det=True, **kw)
+        b = renderer.render_hierarchical(_args(sc, 16, False), *rays, 16, ndc_of, det=True, **kw)
+    assert torch.equal(a["z_vals"], b["z_vals"])
+    close(a["rgb_map"][0], b["rgb_map"][0].cpu().numpy(), atol=2e-2, rtol=0, name="fused fine pass/rgb")

@@ -29,6 +29,11 @@ VARIANTS = [("fused_%s_%s" % (pt, tag),
              # replaces (MI355X_MICROARCH.md, 'price of one filler beside MFMAs'): +1.0 % / +1.8 % on the one- / two-net
              # feature kernels, -0.7 % on the featureless one, which keeps it (profiles/r03_ab_slp_ring.txt)
              (["-fno-slp-vectorize"] if (nts or ntd) else []))
+            # (tried and not kept, profiles/r03_ab_mcache.txt: "-DZEST_CHUNK=8 -DZEST_SLOTS=8 -DZEST_AHEAD=4
+            # -DZEST_MCACHE_JB=5" for the 16-bit kernels with two feature k-tiles - a 64 KiB weight ring and, in the LDS
+            # that frees, 5 of the 8 row blocks of the modulation m per wave (mlp_engine.cuh): 9.7 % fewer MFMAs, +2.7 % /
+            # +1.5 % on the one- / two-net kernels, but m rounded to 16 bits moves 0.7 % of the rays of the full-size
+            # comparison past its bound, so the recompute in fp32 stays)
             for tag, nts, dyn, ntd, v2 in _SHAPES for pt, ep in _PRECS]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",

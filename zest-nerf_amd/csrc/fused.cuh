@@ -386,11 +386,17 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
     // while the other net runs (registers the engine needs: the two-net kernels spilled them before)
     constexpr int kFdBytes = (DYN && MOD_D && ZEST_EARLY_DYN_GATHER) ? kFusedWaves * CB * (NT_FEAT_D / 2) * NP * 1024 : 0;
     constexpr int kStBytes = DYN ? kFusedWaves * 32 * 24 : 0;
+    // modulation cache (mlp_engine.cuh ZEST_MCACHE_JB): kMcJB row blocks of m per wave, [row block][column block][lane] x 16 B;
+    // the two nets use it one after the other
+    constexpr bool kMc = mcache_for(EP, MOD_S, NT_FEAT_S / 2) || (DYN && mcache_for(EP, MOD_D, NT_FEAT_D / 2));
+    constexpr int kMcWaveBytes = kMc ? kMcJB * CB * 1024 : 0;
     __shared__ __attribute__((aligned(16))) char lds[kRingUnits * 1024 + 2 * kMaxViews * kCamStride * 4 +
                                                      kFusedWaves * 32 * 8 + 2 * kSlots * 4 +
                                                      kFusedWaves * kPartialFloats * 4 + kFusedWaves * 32 * 16 +
-                                                     kFdBytes + kStBytes + 2 * kCarryFloats * 4];
+                                                     kFdBytes + kStBytes + 2 * kCarryFloats * 4 +
+                                                     kFusedWaves * kMcWaveBytes];
     static_assert(sizeof(lds) <= 163840, "LDS budget of one workgroup per CU");
+    static_assert((sizeof(lds) - kFusedWaves * kMcWaveBytes) % 16 == 0, "the modulation cache starts 16-byte aligned");
     float *cams_s = reinterpret_cast<float *>(lds + kRingUnits * 1024), *cams_d = cams_s + kMaxViews * kCamStride;
     float2 *zd_lds = reinterpret_cast<float2 *>(cams_d + kMaxViews * kCamStride);
     constexpr bool PROJ = EP != ZEST_PREC_F16X3;         // 16-bit operand modes: fast projection
@@ -402,6 +408,7 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
     uint4 *fd_lds = reinterpret_cast<uint4 *>(x_lds + kFusedWaves * 32);                   // [waves][CB][k-tile][part][64]
     float2 *st_lds = reinterpret_cast<float2 *>(reinterpret_cast<char *>(fd_lds) + kFdBytes);   // [waves][3][32]
     float *carry_lds = reinterpret_cast<float *>(reinterpret_cast<char *>(st_lds) + kStBytes);  // [2][kCarryFloats]
+    char *mc_lds = lds + sizeof(lds) - kFusedWaves * kMcWaveBytes;                              // 16-byte aligned (sizes above)
 #ifdef ZEST_RING_FLAGS
     Ring::init_flags(ring_flags);
 #endif
@@ -418,6 +425,9 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
 #endif
     };
     tiles.init_addr();
+    if constexpr (kMc)
+        tiles.init_mcache((unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)mc_lds +
+                          (unsigned)wave * kMcWaveBytes + (unsigned)lane0 * 16u);
     tiles.prologue();
 
     // The workgroup's blocks.  Workgroups are numbered so that those of one XCD (equal blockIdx % 8: one L2)
@@ -571,7 +581,7 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
         };
         ZEST_STAMP(st_enc);
         if constexpr (ZEST_REBUILD_PTS) {
-            engine_forward<EP, CB, 4, MOD_S, NT_FEAT_S, V2S>(tiles, unit, pts_static, feat_s,
+            engine_forward<EP, CB, 4, MOD_S, NT_FEAT_S, V2S, true>(tiles, unit, pts_static, feat_s,
                                                         views_of(a.st, cams_s), head_s, rgb_s);
         } else {
             OpArr<2, NP> pts_keep[CB];
@@ -580,7 +590,7 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
 #pragma unroll
                 for (int cb = 0; cb < CB; cb++) o[cb] = pts_keep[cb];
             };
-            engine_forward<EP, CB, 4, MOD_S, NT_FEAT_S, V2S>(tiles, unit, pts_copy, feat_s,
+            engine_forward<EP, CB, 4, MOD_S, NT_FEAT_S, V2S, true>(tiles, unit, pts_copy, feat_s,
                                                         views_of(a.st, cams_s), head_s, rgb_s);
         }
         ZEST_STAMP(st_eng);
@@ -637,7 +647,7 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
             }
             ZEST_STAMP(st_comp);
             if constexpr (ZEST_REBUILD_PTS) {
-                engine_forward<EP, CB, 6, MOD_D, NT_FEAT_D, false>(tiles, unit, pts_dynamic, feat_d,
+                engine_forward<EP, CB, 6, MOD_D, NT_FEAT_D, false, true>(tiles, unit, pts_dynamic, feat_d,
                                                             views_of(a.dy, cams_d), head_d, rgb_d);
             } else {
                 OpArr<3, NP> pts_keep[CB];
@@ -646,7 +656,7 @@ __global__ __launch_bounds__(kFusedWaves * 64, kFusedWaves * ZEST_FUSED_WG_PER_C
 #pragma unroll
                     for (int cb = 0; cb < CB; cb++) o[cb] = pts_keep[cb];
                 };
-                engine_forward<EP, CB, 6, MOD_D, NT_FEAT_D, false>(tiles, unit, pts_copy, feat_d,
+                engine_forward<EP, CB, 6, MOD_D, NT_FEAT_D, false, true>(tiles, unit, pts_copy, feat_d,
                                                             views_of(a.dy, cams_d), head_d, rgb_d);
             }
             ZEST_STAMP(st_eng);

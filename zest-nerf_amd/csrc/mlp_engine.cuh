@@ -297,6 +297,12 @@ struct RingTiles {
     // materialises every `const + lane * 16` beyond the first 64 KiB as a loop-invariant VGPR of
     // its own: ~60 registers of addresses that crowd out operands and end in scratch.
     mutable unsigned rd_lo = 0, rd_hi = 0, rb_lo = 0, rb_hi = 0;
+    // modulation cache (ZEST_MCACHE_JB, engine_layer): LDS byte address of this lane's 16 bytes in the wave's region
+    mutable unsigned mc = 0;
+    __device__ __forceinline__ void init_mcache(unsigned lds_addr) const {
+        mc = lds_addr;
+        asm volatile("" : "+v"(mc));
+    }
     __device__ __forceinline__ void init_addr() const {
         const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)ring;
         rd_lo = base + lane * 16, rd_hi = rd_lo + 65536, rb_lo = base + grp * 16, rb_hi = rb_lo + 65536;
@@ -451,6 +457,34 @@ __device__ __forceinline__ void engine_fp16_overflow_clamp() {
 #endif
 constexpr int kPrefetch = ZEST_PREFETCH;
 
+// Modulation cache.  m = pts_bias(features) is the same in all eight trunk layers; the engine recomputes it per
+// row block and layer with 2 NKF extra MFMA pairs because 256 values per sample have no room in registers.  A kernel
+// built with ZEST_MCACHE_JB = n > 0 (the fused feature kernels whose ring is 64 KiB: fused.cuh) keeps the first n
+// row blocks of m in LDS instead, rounded to the operand type: layer 0 computes them as before and stores them (one
+// ds_write_b128 per column block), layers 1-7 skip those row blocks' modulation tiles - their stream units are
+// walked (touch) but neither read nor multiplied - and read m back (one ds_read_b128 per column block, unpacked
+// with two integer ops per pair).  With two feature k-tiles that removes 8 of the 40 MFMAs and 4 of the 20 tile
+// reads of a cached row block; with one k-tile the unpacking costs what the 4 MFMAs did, so only nets with
+// NKF >= 2 take it.  MC: 0 = off, 1 = compute + store (layer 0), 2 = load (layers 1-7).
+#ifndef ZEST_MCACHE_JB
+#define ZEST_MCACHE_JB 0
+#endif
+constexpr int kMcJB = ZEST_MCACHE_JB;
+constexpr bool mcache_for(int EP, bool mod, int nkf) { return kMcJB > 0 && mod && nkf >= 2 && EP != ZEST_PREC_F16X3; }
+
+template <int EP>
+__device__ __forceinline__ void unpack_pairs(const v4u q, float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if constexpr (EP == ZEST_PREC_BF16) {
+            v[2 * i] = __uint_as_float(q[i] << 16), v[2 * i + 1] = __uint_as_float(q[i] & 0xFFFF0000u);
+        } else {
+            const f32x2_t f = __builtin_convertvector(__builtin_bit_cast(f16x2_t, q[i]), f32x2_t);
+            v[2 * i] = f[0], v[2 * i + 1] = f[1];
+        }
+    }
+}
+
 // What is fetched ahead for one row block: its bias initialisers and its first tiles.
 template <int NP>
 struct RowBlockPre {
@@ -481,7 +515,7 @@ struct NoSink {
 // 2 880 MFMAs, on the port the engine is short of (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost') - and a
 // scalar branch per row block cuts the unrolled network into basic blocks the register allocator answers with
 // ~200 spills.
-template <int EP, int CB, int NJB, int NKA, int NKB, bool MOD, int NKF, bool RELU, int MODE, bool V2, class Tiles,
+template <int EP, int CB, int NJB, int NKA, int NKB, bool MOD, int NKF, bool RELU, int MODE, bool V2, int MC, class Tiles,
           class Sink = NoSink>
 __device__ __forceinline__ void engine_layer(const Tiles &tiles, int &unit,
                                              const OpArr<NKA, ep_parts(EP)> (&opa)[CB],
@@ -495,24 +529,32 @@ __device__ __forceinline__ void engine_layer(const Tiles &tiles, int &unit,
     static_assert(T >= 1, "empty layer");
     // a sink wants the activated fp32 values: only the plain inference layer rounds first
     constexpr bool kPackedRelu = ZEST_PACKED_RELU && RELU && MODE == 0 && EP != ZEST_PREC_F16X3 && __is_same(Sink, NoSink);
-    auto preload = [&](RowBlockPre<NP> &p, int u0) {            // u0: the row block's header unit
+    static_assert(MC == 0 || (MOD && MODE == 0 && NJB == 8), "the modulation cache serves modulated trunk layers");
+    // first tile a row block executes: its modulation tiles are skipped where m comes from the cache
+    auto k0_of = [](int jb) { return (MC == 2 && jb < kMcJB) ? NM : 0; };
+    auto preload = [&](RowBlockPre<NP> &p, int u0, int k0) {    // u0: the row block's header unit
 #pragma unroll
         for (int rt = 0; rt < 2; rt++) {
             p.bias[rt] = tiles.load_bias(u0, 0, rt);
-            if (MOD) p.mbias[rt] = tiles.load_bias(u0, 1, rt);
+            if (MOD && k0 == 0) p.mbias[rt] = tiles.load_bias(u0, 1, rt);
         }
 #pragma unroll
-        for (int k = 0; k < kPrefetch; k++)
-            if (k < T) {
+        for (int k = 0; k < k0; k++)                            // skipped units: the ring's chunks are still entered in order
 #pragma unroll
-                for (int pt = 0; pt < NP; pt++) p.win[k][pt] = tiles.load(u0 + 1 + NP * k + pt);
+            for (int pt = 0; pt < NP; pt++) tiles.touch(u0 + 1 + NP * k + pt);
+#pragma unroll
+        for (int k = 0; k < kPrefetch; k++)
+            if (k0 + k < T) {
+#pragma unroll
+                for (int pt = 0; pt < NP; pt++) p.win[k][pt] = tiles.load(u0 + 1 + NP * (k0 + k) + pt);
             }
     };
     RowBlockPre<NP> pre;
-    preload(pre, unit);
+    preload(pre, unit, k0_of(0));
 #pragma unroll
     for (int jb = 0; jb < NJB; jb++) {
-        const int u0 = unit;
+        const int u0 = unit, k0 = k0_of(jb);
+        const bool mc_rd = MC == 2 && jb < kMcJB, mc_wr = MC == 1 && jb < kMcJB;
         // acc: the hi*hi products (all products of the one-part types); corr: hi*lo + lo*hi, scaled 2^11
         f32x4 acc[2][CB], macc[2][CB], corr[2][CB], mcorr[2][CB];
         bf16x8 win[kPrefetch][NP];
@@ -525,14 +567,14 @@ __device__ __forceinline__ void engine_layer(const Tiles &tiles, int &unit,
 #pragma unroll
             for (int cb = 0; cb < CB; cb++) {
                 acc[rt][cb] = pre.bias[rt];
-                if (MOD) macc[rt][cb] = pre.mbias[rt];
+                if (MOD && !mc_rd) macc[rt][cb] = pre.mbias[rt];
                 if (X3) corr[rt][cb] = f32x4{0.f, 0.f, 0.f, 0.f}, mcorr[rt][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
-        for (int k = 0; k < T; k++) {
+        for (int k = k0; k < T; k++) {
             bf16x8 a[NP];
 #pragma unroll
-            for (int pt = 0; pt < NP; pt++) a[pt] = win[k % kPrefetch][pt];
+            for (int pt = 0; pt < NP; pt++) a[pt] = win[(k - k0) % kPrefetch][pt];
             const int rt = k % 2, kt = (k < NM ? k : k - NM) / 2;          // compile-time after unrolling
 #pragma unroll
             for (int cb = 0; cb < CB; cb++) {
@@ -559,14 +601,19 @@ __device__ __forceinline__ void engine_layer(const Tiles &tiles, int &unit,
             }
             if (k + kPrefetch < T) {
 #pragma unroll
-                for (int pt = 0; pt < NP; pt++) win[k % kPrefetch][pt] = tiles.load(u0 + 1 + NP * (k + kPrefetch) + pt);
+                for (int pt = 0; pt < NP; pt++) win[(k - k0) % kPrefetch][pt] = tiles.load(u0 + 1 + NP * (k + kPrefetch) + pt);
             }
 #ifdef ZEST_SCHED_PIN
             __builtin_amdgcn_sched_barrier(0);      // keep the hand-made read-ahead distance
 #endif
         }
+        v4u mq[CB];
+        if (mc_rd) {                                             // in flight while the last MFMAs drain
+#pragma unroll
+            for (int cb = 0; cb < CB; cb++) mq[cb] = *Tiles::template lds_at<v4u>(tiles.mc + (jb * CB + cb) * 1024);
+        }
         unit = u0 + 1 + NP * T;
-        if (jb + 1 < NJB) preload(pre, unit);                   // in flight during the epilogue
+        if (jb + 1 < NJB) preload(pre, unit, k0_of(jb + 1));                   // in flight during the epilogue
         tiles.flush();
 #pragma unroll
         for (int cb = 0; cb < CB; cb++) {
@@ -577,12 +624,26 @@ __device__ __forceinline__ void engine_layer(const Tiles &tiles, int &unit,
                 if (X3) v[i] = fmaf(corr[i >> 2][cb][i & 3], kLoUnscale, v[i]);
             }
             if (MOD) {
+                float mv[8];
+                if (mc_rd) {
+                    unpack_pairs<EP>(mq[cb], mv);
+                } else {
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    float mv = macc[i >> 2][cb][i & 3];
-                    if (X3) mv = fmaf(mcorr[i >> 2][cb][i & 3], kLoUnscale, mv);
-                    v[i] = V2 ? v[i] + mv : v[i] * mv;
+                    for (int i = 0; i < 8; i++) {
+                        mv[i] = macc[i >> 2][cb][i & 3];
+                        if (X3) mv[i] = fmaf(mcorr[i >> 2][cb][i & 3], kLoUnscale, mv[i]);
+                    }
                 }
+                if (mc_wr) {
+                    if constexpr (!X3) {
+                        const uint4 q = make_uint4(pack_pair<EP>(mv[0], mv[1]), pack_pair<EP>(mv[2], mv[3]),
+                                                   pack_pair<EP>(mv[4], mv[5]), pack_pair<EP>(mv[6], mv[7]));
+                        *(__attribute__((address_space(3))) v4u *)(uintptr_t)(tiles.mc + (jb * CB + cb) * 1024) =
+                            __builtin_bit_cast(v4u, q);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++) v[i] = V2 ? v[i] + mv[i] : v[i] * mv[i];
             }
             if (RELU && !kPackedRelu) {
 #pragma unroll
@@ -607,12 +668,14 @@ __device__ __forceinline__ void engine_layer(const Tiles &tiles, int &unit,
 // out copies);
 // `views_fn(views)` builds the direction operand when it is first needed (op 10).  Results per column block: head (lane group g: rows 4g .. 4g+3 of the head
 // tile; row 0 alpha, rows 1.. extra heads) and rgb (group 0: rows 0-2), raw.
-template <int EP, int CB, int NU_PTS, bool MOD, int NU_FEAT, bool V2, class Tiles, class PtsFn, class ViewsFn, class Sink = NoSink>
+template <int EP, int CB, int NU_PTS, bool MOD, int NU_FEAT, bool V2, bool MCACHE = false, class Tiles, class PtsFn, class ViewsFn,
+          class Sink = NoSink>
 __device__ __forceinline__ void engine_forward(const Tiles &tiles, int &unit, PtsFn pts_fn,
                                                const OpArr<NU_FEAT / 2, ep_parts(EP)> (&feat)[CB], ViewsFn views_fn,
                                                f32x4 (&head)[CB], f32x4 (&rgb)[CB], const Sink &sink = Sink()) {
     constexpr int KP = NU_PTS / 2, KF = NU_FEAT / 2, NP = ep_parts(EP);
     static_assert(NU_PTS % 2 == 0 && NU_FEAT % 2 == 0, "units per row block come in row-tile pairs");
+    constexpr int MC0 = (MCACHE && mcache_for(EP, MOD, KF)) ? 1 : 0, MCL = MC0 ? 2 : 0;   // layer 0 stores m, 1-7 load it
     OpArr<8, NP> hA[CB], hB[CB];
     OpArr<0, NP> none[CB];
     f32x4 unused[CB];
@@ -620,27 +683,27 @@ __device__ __forceinline__ void engine_forward(const Tiles &tiles, int &unit, Pt
     {
         OpArr<KP, NP> pts[CB];
         pts_fn(pts, 0);
-        engine_layer<EP, CB, 8, KP, 0, MOD, KF, true, 0, V2>(tiles, unit, pts, none, feat, hA, unused, 0, sink);
+        engine_layer<EP, CB, 8, KP, 0, MOD, KF, true, 0, V2, MC0>(tiles, unit, pts, none, feat, hA, unused, 0, sink);
     }
-    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0, V2>(tiles, unit, hA, none, feat, hB, unused, 1, sink);
-    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0, V2>(tiles, unit, hB, none, feat, hA, unused, 2, sink);
-    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0, V2>(tiles, unit, hA, none, feat, hB, unused, 3, sink);
-    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0, V2>(tiles, unit, hB, none, feat, hA, unused, 4, sink);
+    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0, V2, MCL>(tiles, unit, hA, none, feat, hB, unused, 1, sink);
+    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0, V2, MCL>(tiles, unit, hB, none, feat, hA, unused, 2, sink);
+    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0, V2, MCL>(tiles, unit, hA, none, feat, hB, unused, 3, sink);
+    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0, V2, MCL>(tiles, unit, hB, none, feat, hA, unused, 4, sink);
     {
         // `token` is a value layer 4 has just produced: a builder that ties its address arithmetic to it
         // cannot be scheduled ahead of layers 1-4 (where its registers would be live all along)
         OpArr<KP, NP> pts[CB];
         pts_fn(pts, (int)hA[CB - 1].t[0][7][0]);
-        engine_layer<EP, CB, 8, KP, 8, MOD, KF, true, 0, V2>(tiles, unit, pts, hA, feat, hB, unused, 5, sink);
+        engine_layer<EP, CB, 8, KP, 8, MOD, KF, true, 0, V2, MCL>(tiles, unit, pts, hA, feat, hB, unused, 5, sink);
     }
-    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0, V2>(tiles, unit, hB, none, feat, hA, unused, 6, sink);
-    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0, V2>(tiles, unit, hA, none, feat, hB, unused, 7, sink);
+    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0, V2, MCL>(tiles, unit, hB, none, feat, hA, unused, 6, sink);
+    engine_layer<EP, CB, 8, 8, 0, MOD, KF, true, 0, V2, MCL>(tiles, unit, hA, none, feat, hB, unused, 7, sink);
     // trunk output in hB
-    engine_layer<EP, CB, 1, 8, 0, false, KF, false, 1, V2>(tiles, unit, hB, none, feat, hA, head);
-    engine_layer<EP, CB, 8, 8, 0, false, KF, false, 0, V2>(tiles, unit, hB, none, feat, hA, unused, 8, sink);
+    engine_layer<EP, CB, 1, 8, 0, false, KF, false, 1, V2, 0>(tiles, unit, hB, none, feat, hA, head);
+    engine_layer<EP, CB, 8, 8, 0, false, KF, false, 0, V2, 0>(tiles, unit, hB, none, feat, hA, unused, 8, sink);
     OpArr<1, NP> views[CB];
     views_fn(views);
-    engine_layer<EP, CB, 4, 8, 1, false, KF, true, 0, V2>(tiles, unit, hA, views, feat, hB, unused, 9, sink);
+    engine_layer<EP, CB, 4, 8, 1, false, KF, true, 0, V2, 0>(tiles, unit, hA, views, feat, hB, unused, 9, sink);
     // rgb: 128 hidden features = first 4 k-tiles of hB
     OpArr<4, NP> h128[CB];
 #pragma unroll
@@ -649,7 +712,7 @@ __device__ __forceinline__ void engine_forward(const Tiles &tiles, int &unit, Pt
         for (int pt = 0; pt < NP; pt++)
 #pragma unroll
             for (int k = 0; k < 4; k++) h128[cb].t[pt][k] = hB[cb].t[pt][k];
-    engine_layer<EP, CB, 1, 4, 0, false, KF, false, 1, V2>(tiles, unit, h128, none, feat, hA, rgb);
+    engine_layer<EP, CB, 1, 4, 0, false, KF, false, 1, V2, 0>(tiles, unit, h128, none, feat, hA, rgb);
     tiles.finish(unit, unit0 + stream_units(NU_PTS, MOD ? NU_FEAT : 0, NP));
     unit = unit0 + stream_units(NU_PTS, MOD ? NU_FEAT : 0, NP);
 }

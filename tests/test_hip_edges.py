@@ -103,3 +103,19 @@ def test_refused_arguments_raise_with_a_message(hip):
 def _bad_mlp_call(zh):
     _, inp, desc, tab = _mlp_setup("mlp_static_mvs20")
     return desc, zh.PREC_F32, zh.mlp_pack(desc, zh.PREC_F32, tab), _z(8, desc.in_ch + 1)
+
+
+def test_second_device_context(hip):
+    """include/zest_render.h, "Devices": the library's own device-side state (gather tables of zest_mlp_pack, train16
+    tables, rocBLAS handle) is keyed on the current device, so the same net renders on another device of the process.
+    One-GPU boxes (the driver's test box) skip; the keying itself is also exercised by every test on device 0."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two HIP devices")
+    import zest_hip as zh
+    zhh, inp, desc, tab = _mlp_setup("mlp_static_mvs20")
+    x0 = torch.rand(96, desc.in_ch, device="cuda:0")
+    y0 = zh.mlp_fwd(desc, zh.PREC_BF16, zh.mlp_pack(desc, zh.PREC_BF16, tab), x0)
+    with torch.cuda.device(1):
+        tab1 = [t.to("cuda:1") if t is not None else None for t in tab]
+        y1 = zh.mlp_fwd(desc, zh.PREC_BF16, zh.mlp_pack(desc, zh.PREC_BF16, tab1), x0.to("cuda:1"))
+    assert torch.equal(y0.cpu(), y1.cpu())

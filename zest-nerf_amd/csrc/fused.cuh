@@ -230,6 +230,14 @@ __device__ __forceinline__ void encode_feat_operand(const FusedNet &n, const flo
 #ifdef ZEST_EXPERIMENT_NO_GATHER      // timing experiment only: features are zero
     valid = false;
 #endif
+#ifdef ZEST_EXPERIMENT_FAKE_FEAT      // timing experiment only: no lookups, but feature values with realistic bit patterns
+    if (valid) {                      // (zero features let the chip hold a higher clock: not a clean knock-out)
+#pragma unroll
+        for (int i = 0; i < NK * 8; i++)
+            v[i] = __builtin_amdgcn_fractf(ndc[0] * (13.37f + (float)i) + ndc[2] * 7.1f + (float)grp * 0.31f) - 0.25f;
+    }
+    valid = false;
+#endif
     const int rv = feat_volume_round(n.V);
     if (valid) {
         float vv[4] = {0.f, 0.f, 0.f, 0.f};

@@ -136,3 +136,42 @@ def test_fused_fine_pass(hip):
         b = renderer.render_hierarchical(_args(sc, 16, False), *rays, 16, ndc_of, det=True, **kw)
     assert torch.equal(a["z_vals"], b["z_vals"])
     close(a["rgb_map"][0], b["rgb_map"][0].cpu().numpy(), atol=2e-2, rtol=0, name="fused fine pass/rgb")
+
+
+def test_configs3_coarse_plus_fine_at_full_size(hip):
+    """BASELINE configs[3] as written: 4096 rays, 128 coarse + 64 importance = 192 samples, full ZeST inference, fine
+    pass through the fused bf16 kernel.  Size-independent properties: merged depths ascending and inside the coarse
+    range, 192 per ray; maps finite, colours in [0, 1], accumulated weights <= 1; the coarse maps are the single-pass
+    render; the same call per operator agrees with the fused one (bf16 tolerance, one ray per thousand excused)."""
+    import bench
+    import zest_renderer as renderer
+    import zest_utils as utils
+    d = bench.build_workload("nsff_zest_val_1024x128", 3, torch.device("cuda:0"), rays=4096, lively=False)
+    inv = torch.tensor([512 - 1.0, 288 - 1.0])
+
+    def ndc_of(p):
+        return utils.get_ndc_coordinate(d.cam["w2cs"][:, 0], d.cam["intrinsics"][:, 0], p, inv, near=2.0, far=6.0, pad=24)
+    assert (ndc_of(d.t["rays_pts"]) - d.t["rays_ndc"]).abs().max().item() < 5e-5
+    kw = dict(volume_feature_static=d.vol_s, volume_feature_dynamic=d.vol_d, imgs=d.imgs, neighbour_frames=d.nb_imgs,
+              im_cam_mat=d.cam, nb_cam_mat=d.nb_cam, network_fn=d.net_s, network_fn_dy=d.net_d, embedding_pts=d.emb[0],
+              embedding_xyzt=d.emb[1], embedding_dir=d.emb[2], ref_frame_idx=0.1, num_frames=24, scene_flow=True, val=True)
+    rays = [d.t[k] for k in ("rays_pts", "rays_ndc", "depth_candidates", "rays_dir")]
+    d.args.precision = 16
+    with torch.no_grad():
+        d.args.zest_maps_only = True
+        out = renderer.render_hierarchical(d.args, *rays, 64, ndc_of, det=True, **kw)
+        single = renderer.rendering(d.args, *rays, **kw)
+        d.args.zest_maps_only = False
+        perop = renderer.render_hierarchical(d.args, *rays, 64, ndc_of, det=True, **kw)
+    z = out["z_vals"]
+    assert z.shape == (1, 4096, 192) and bool((z[..., 1:] >= z[..., :-1]).all())
+    assert z.min() >= rays[2].min() - 1e-6 and z.max() <= rays[2].max() + 1e-6
+    for k in ("rgb_map", "rgb_map_ref", "rgb_map_ref_dy", "depth_map", "depth_map_ref", "weights_map_dd"):
+        assert torch.isfinite(out[k]).all(), k
+    for k in ("rgb_map", "rgb_map_ref"):
+        assert out[k].min() >= -1e-3 and out[k].max() <= 1.0 + 1e-3
+    assert out["weights_map_dd"].max() <= 1.0 + 1e-3
+    assert torch.equal(out["rgb_map_coarse"], perop["rgb_map_coarse"])
+    close_maps = (out["rgb_map_ref"][0] - perop["rgb_map_ref"][0]).abs().max(-1).values
+    assert (close_maps > 2e-2).float().mean().item() <= 1e-3, close_maps.max().item()
+    assert (single["rgb_map_ref"] - out["rgb_map_ref"]).abs().mean().item() < 0.05      # same scene, more samples

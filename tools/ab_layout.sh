@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B of the encoding-volume layout on the GPU box: the round-2 library (plane-major [D][H][W][8], kept as
+# A/B of the encoding-volume layout on the GPU box: the round-2 library (plane-major [D][H][W][8]; build it from
+# commit ecdb515 in a git worktree and copy its libzest_hip.so to
 # zest-nerf_amd/libzest_hip_r02layout.so during round 3) against the current one ([H][W][D][8], depth innermost),
 # same process order, feature workloads with random and with coherent (pixel-grid) rays.
 for wl in nsff_static_mvs_1024x128 nsff_static_mvs_grid_1024x128 nsff_zest_val_1024x128 nsff_zest_val_grid_1024x128; do

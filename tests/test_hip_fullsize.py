@@ -54,6 +54,24 @@ def test_fused_equals_per_op_path_at_full_size(hip, name):
     assert (acc >= -1e-5).all() and (acc <= 1 + 1e-4).all()
 
 
+@pytest.mark.parametrize("lively", [True, False], ids=["he-scale", "default-scale"])
+@pytest.mark.parametrize("name", ["nsff_static_1024x128", "nsff_static_mvs_1024x128", "nsff_zest_val_1024x128"])
+def test_fp32_mode_fused_equals_exact_fp32_per_op_at_full_size_per_element(hip, name, lively):
+    """The FULL 1024 x 128 batches in fp32 mode, per element, no ray excused: the fused single-launch renderer
+    (split-fp16 operand pairs) against the per-operator path with EXACT fp32 products (v_mfma_f32_32x32x2_f32 MLP,
+    accurate sincos, the reference's projection order) at BASELINE.json's tolerance 1e-4 abs + 1e-3 rel.  The
+    per-operator exact path is the one the reference fixtures and the oracle pin per element
+    (tests/test_hip_render.py, tests/test_hip_precision.py: fixtures and 256-320-ray subsets - what a CPU oracle
+    affords); this test carries that to every ray of the batch."""
+    d = _workload(name, lively=lively)
+    d.args.precision, d.args.zest_fp32_exact = 32, True
+    f, p = _maps(d, True), _maps(d, False)
+    for k in f:
+        if k in ("acc_map", "zest_packed_maps"):
+            continue
+        close(f[k][0], p[k][0].double().cpu().numpy(), atol=1e-4, rtol=1e-3, name="%s/%s" % (name, k))
+
+
 @pytest.mark.parametrize("rays", [None, 512])          # BASELINE configs[3]: the full batch on one GPU, the 1-of-8 shard
 def test_configs3_ray_ranges_equal_the_dense_shape_bit_for_bit(hip, rays):
     """4096 x 192 (6 blocks per ray): the default pass shape - a range of whole rays per workgroup, rays that

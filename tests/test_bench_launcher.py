@@ -51,3 +51,21 @@ def test_rank_count_mismatch_is_an_error():
     r = _run(["--dry", "--gpus", "2", "--steps", "1", "--warmup", "0"],
              env={"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"})
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["bf16", "f16x3"])
+def test_bench_json_line_on_the_gpu(mode):
+    """The real (non --dry) bench on one GPU, short: ONE JSON line with the contract's keys, the roofline object and
+    the other operand types in `modes` - also when the headline mode is f16x3 (the line used to die on a KeyError
+    after all the timing was done)."""
+    r = _run(["--steps", "5", "--warmup", "2", "--mode", mode, "--no-cpu-baseline"], timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _json_line(r)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in out, k
+    assert out["dtype"] == mode and out["n_gpus"] == 1 and out["steps"] == 5 and out["value"] > 1e5
+    assert out["roofline"]["bound"] == "mfma" and 0.05 < out["roofline"]["frac"] < 1.0
+    assert sorted(out["modes"]) == sorted(m for m in ("bf16", "f16", "f16x3") if m != mode)
+    assert out["config"]["workload"] == "nsff_static_1024x128"

@@ -210,6 +210,14 @@ int zest_encode_fwd(const float *ndc, const float *pts, const float *rays_dir, i
                     const float *imgs_cl, int V, int H, int W,
                     const float *w2cs, const float *intrinsics,
                     float *x, void *stream);
+/* The same entry point under the name SURVEY.md 8(b) gives it (the survey lists the launchers a replacement exports
+ * as zest_gather_encode_fwd and zest_pack_weights; the reference itself has no FFI that would bind either name). */
+int zest_gather_encode_fwd(const float *ndc, const float *pts, const float *rays_dir, int R, int S,
+                           int has_time, float t,
+                           const float *vol_cl, int D, int Hv, int Wv,
+                           const float *imgs_cl, int V, int H, int W,
+                           const float *w2cs, const float *intrinsics,
+                           float *x, void *stream);
 
 /* ---- ray sampling (the step in front of the renderer) -----------------------------
  * Per-sample part of build_rays_base (reference utils.py:361-387): depth candidates
@@ -315,6 +323,9 @@ int zest_mlp_train16_bwd(const zest_mlp_desc *desc, const void *packed_bwd, cons
  * 2*ZEST_P_COUNT device pointers (weight, bias per ZEST_P_* slot, NULL where absent). */
 size_t zest_mlp_packed_bytes(const zest_mlp_desc *desc, int precision);
 int    zest_mlp_pack(const zest_mlp_desc *desc, int precision, const float *const *params,
+                     void *packed, void *stream);
+/* zest_mlp_pack under SURVEY.md 8(b)'s name */
+int    zest_pack_weights(const zest_mlp_desc *desc, int precision, const float *const *params,
                      void *packed, void *stream);
 
 /* MVSNeRF.forward / Renderer.forward (reference networks.py:150-221, 283-319):

@@ -32,3 +32,15 @@ extern "C" int zest_device_info(int *cu_count, int *clock_khz, char *name, size_
     }
     return 0;
 }
+
+// SURVEY.md 8(b)'s names for two entry points (include/zest_render.h)
+extern "C" int zest_gather_encode_fwd(const float *ndc, const float *pts, const float *rays_dir, int R, int S, int has_time,
+                                      float t, const float *vol_cl, int D, int Hv, int Wv, const float *imgs_cl, int V,
+                                      int H, int W, const float *w2cs, const float *intrinsics, float *x, void *stream) {
+    return zest_encode_fwd(ndc, pts, rays_dir, R, S, has_time, t, vol_cl, D, Hv, Wv, imgs_cl, V, H, W, w2cs, intrinsics, x,
+                           stream);
+}
+extern "C" int zest_pack_weights(const zest_mlp_desc *desc, int precision, const float *const *params, void *packed,
+                                 void *stream) {
+    return zest_mlp_pack(desc, precision, params, packed, stream);
+}

@@ -88,6 +88,8 @@ _SIGS = {
     "zest_color_lookup_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "zest_encode_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp, _i, _i, _i, _vp, _i, _i, _i,
                              _vp, _vp, _vp, _vp]),
+    "zest_gather_encode_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp, _i, _i, _i, _vp, _i, _i, _i,
+                                    _vp, _vp, _vp, _vp]),            # = zest_encode_fwd (SURVEY 8(b)'s name)
     "zest_build_rays_fwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i,
                                  _vp, _vp, _vp, _vp, _vp]),
     "zest_sample_pdf_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
@@ -111,6 +113,7 @@ _SIGS = {
                                   C.POINTER(_vp), _i, _vp]),
     "zest_mlp_packed_bytes": (_sz, [C.POINTER(MlpDesc), _i]),
     "zest_mlp_pack": (_i, [C.POINTER(MlpDesc), _i, C.POINTER(_vp), _vp, _vp]),
+    "zest_pack_weights": (_i, [C.POINTER(MlpDesc), _i, C.POINTER(_vp), _vp, _vp]),       # = zest_mlp_pack
     "zest_mlp_fwd": (_i, [C.POINTER(MlpDesc), _i, _vp, _vp, _i, _vp, _vp]),
     "zest_render_fused_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, C.POINTER(MlpDesc), _vp,
                                    C.POINTER(ViewSet), C.POINTER(MlpDesc), _vp, C.POINTER(ViewSet),

@@ -171,16 +171,17 @@ def _hip_render_grads(case, precision):
     c, sc = gc.CASES[case], gc.build(case)
     sf = sc["scene_flow"]
     ns, nd = build_nets(sc)
+    dy = sf and sc["use_mvs_dy"]
     vol_s = G(sc["vol_static"]).requires_grad_(True)
-    vol_d = G(sc["vol_dynamic"]).requires_grad_(True) if sf else None
+    vol_d = G(sc["vol_dynamic"]).requires_grad_(True) if dy else None
     args = SimpleNamespace(netchunk=1024, feat_dim=sc["feat_dim"], feat_dim_dy=24, img_downscale=1.0,
                            use_color_volume=False, net_type="v0", precision=precision)
     cam = {"w2cs": G(sc["w2cs"]), "intrinsics": G(sc["intrinsics"])}
-    nb_cam = {"w2cs": G(sc["nb_w2cs"]), "intrinsics": G(sc["nb_intrinsics"])} if sf else None
+    nb_cam = {"w2cs": G(sc["nb_w2cs"]), "intrinsics": G(sc["nb_intrinsics"])} if dy else None
     ret = renderer.rendering(
         args, G(sc["rays_pts"]), G(sc["rays_ndc"]), G(sc["depth_candidates"]), G(sc["rays_dir"]),
         volume_feature_static=vol_s, volume_feature_dynamic=vol_d, imgs=G(sc["imgs"]),
-        neighbour_frames=G(sc["nb_imgs"]) if sf else None, im_cam_mat=cam, nb_cam_mat=nb_cam, network_fn=ns,
+        neighbour_frames=G(sc["nb_imgs"]) if dy else None, im_cam_mat=cam, nb_cam_mat=nb_cam, network_fn=ns,
         network_fn_dy=nd, embedding_pts=networks.Embedding(3, 10), embedding_xyzt=networks.Embedding(4, 10),
         embedding_dir=networks.Embedding(3, 4), chain_bwd=c.get("chain_bwd", False),
         chain_5frames=c.get("chain_5frames", False), ref_frame_idx=gc.REF_FRAME_IDX, num_frames=gc.NUM_FRAMES,
@@ -189,7 +190,7 @@ def _hip_render_grads(case, precision):
     loss = sum((G(W[k]) * ret[k][0]).sum() for k in W)
     loss.backward()
     got = {"vol_static": vol_s.grad[0]}
-    if sf:
+    if dy:
         got["vol_dynamic"] = vol_d.grad[0]
     for tag, net in (("static", ns), ("dynamic", nd)):
         if net is not None:
@@ -249,3 +250,19 @@ def test_split_fns_against_plain_slicing(hip):
     ((ra[0] * w0).sum() + (ra[1] * w1).sum()).backward()
     ((rb[0] * w0).sum() + (rb[1] * w1).sum()).backward()
     assert torch.equal(a2.grad, b2.grad)
+
+
+def test_bf16_training_without_a_dynamic_volume(hip):
+    """use_mvs_dy off (reference opt.py:76): the dynamic net has no feature columns, the neighbour-frame pair batch
+    (EncodePairFn) runs without a volume; --precision 16 against --precision 32 of the same train-mode call: loss
+    within 2 %, the static net's and volume's gradients aligned (they do not pass the scene-flow chain), the dynamic
+    net's finite, non-zero and within a factor of two in norm."""
+    l32, g32 = _hip_render_grads("render_zest_nomvsdy", 32)
+    l16, g16 = _hip_render_grads("render_zest_nomvsdy", 16)
+    assert sorted(g16) == sorted(g32) and "vol_dynamic" not in g16
+    assert abs(l16 - l32) <= 2e-2 * max(1.0, abs(l32)), (l16, l32)
+    for grp, cos_min in (("static.", 0.9), ("vol_static", 0.9), ("dynamic.", 0.3)):
+        a, b = _agg(g16, grp), _agg(g32, grp)
+        cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+        ratio = float(np.linalg.norm(a) / (np.linalg.norm(b) + 1e-30))
+        assert np.isfinite(a).all() and cos > cos_min and 0.5 < ratio < 2.0, (grp, cos, ratio)

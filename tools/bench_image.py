@@ -26,7 +26,11 @@ def main():
     ap.add_argument("--chunk", type=int, default=1024)
     ap.add_argument("--precision", type=int, default=16)
     ap.add_argument("--images", type=int, default=3)
+    ap.add_argument("--no-conv-autotune", action="store_true",
+                    help="leave torch.backends.cudnn.benchmark off (the reference's Trainer sets benchmark=True, train.py:1331: "
+                         "MIOpen then times its convolution solvers on first use)")
     a = ap.parse_args()
+    torch.backends.cudnn.benchmark = not a.no_conv_autotune
     H, W = 288, 512
     x = tg._batch(7, H=H, W=W)
     args = tg._args(chunk=a.chunk, precision=a.precision, N_samples=128, pad=24, batch_size=a.chunk)
@@ -47,6 +51,7 @@ def main():
     per_img, per_vol = (t1 - t0) / a.images, (t2 - t1) / a.images
     rgb = torch.cat(res[1])
     print(json.dumps({"op": "forward_val, %dx%d, %d samples, chunk %d, precision %d" % (H, W, 128, a.chunk, a.precision),
+                      "conv_autotune": bool(torch.backends.cudnn.benchmark),
                       "ms_per_image": round(per_img * 1e3, 2), "ms_volume_builders": round(per_vol * 1e3, 2),
                       "ms_rays_and_render": round((per_img - per_vol) * 1e3, 2),
                       "pixels_per_s": round(H * W / per_img), "finite": bool(torch.isfinite(rgb).all())}))

@@ -176,3 +176,23 @@ def test_training_step_reaches_the_volume_builders(hip):
         grads = {k: p.grad for k, p in enc.named_parameters()}
         assert all(g is not None and torch.isfinite(g).all() for g in grads.values())
         assert grads["feature.conv0.0.conv.weight"].abs().max() > 0 and grads["cost_reg_2.conv0.conv.weight"].abs().max() > 0
+
+
+@pytest.mark.gpu
+def test_forward_val_builds_the_two_volumes_on_two_streams(hip):
+    """Whole-image evaluation builds the static and the dynamic encoding volume side by side on two HIP streams
+    (independent nets and images); the image is the one the serial order gives, bit for bit, also when the call is
+    repeated (the second stream is kept)."""
+    x = _batch(91)
+    outs = []
+    for overlap in (True, False, True):
+        gen = _generator(_args(chunk=256, precision=16, zest_overlap_builders=overlap))
+        res = gen.forward_val(x)
+        assert ("_zest_side_stream" in gen.__dict__) == overlap
+        outs.append([torch.cat(r) for r in res[1:]])
+        if overlap:
+            again = [torch.cat(r) for r in gen.forward_val(x)[1:]]
+            gen.chain_bwd = False
+            assert all(torch.equal(a, b) for a, b in zip(outs[-1], again))
+    for other in outs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(outs[0], other))

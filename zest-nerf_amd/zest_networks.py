@@ -579,11 +579,29 @@ class DyMVSNeRF_G(_Generator):
         """Volumes, unnormalised images and cameras of one batch dict."""
         sc = dict(cams={'w2cs': x['w2cs'], 'intrinsics': x['intrinsics']}, nb_frames=None, nb_cams=None)
         imgs, near_far = x['images'], x['near_fars'][0, 0]
-        sc['vol_s'] = self._volume(self.encoding_net, imgs[:, :-1], x['proj_mats'][:, :-1], near_far, bn_batch_stats)
+        # The two volume builders are independent (different images, different nets).  Without a graph (whole-image
+        # evaluation) the dynamic one runs on a second HIP stream beside the static one: the small convolutions of the
+        # feature pyramids and the tails of the large ones leave CUs idle that the other builder can use.
+        side = None
+        if (self.encoding_net_dy is not None and self.encoding_net is not None and imgs.is_cuda
+                and not torch.is_grad_enabled() and getattr(self.args, 'zest_overlap_builders', True)):
+            side = self.__dict__.get('_zest_side_stream')
+            if side is None or side.device != imgs.device:
+                side = self.__dict__['_zest_side_stream'] = torch.cuda.Stream(device=imgs.device)
         sc['vol_d'] = None
+        if side is not None:
+            cur = torch.cuda.current_stream(imgs.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                sc['vol_d'] = self._volume(self.encoding_net_dy, x['nb_imgs'], x['nb_proj_mats'], near_far, bn_batch_stats)
+        sc['vol_s'] = self._volume(self.encoding_net, imgs[:, :-1], x['proj_mats'][:, :-1], near_far, bn_batch_stats)
         if self.encoding_net_dy is not None:
             sc['nb_cams'] = {'w2cs': x['nb_w2cs'], 'intrinsics': x['nb_intr']}
-            sc['vol_d'] = self._volume(self.encoding_net_dy, x['nb_imgs'], x['nb_proj_mats'], near_far, bn_batch_stats)
+            if side is not None:
+                torch.cuda.current_stream(imgs.device).wait_stream(side)
+                sc['vol_d'].record_stream(torch.cuda.current_stream(imgs.device))
+            else:
+                sc['vol_d'] = self._volume(self.encoding_net_dy, x['nb_imgs'], x['nb_proj_mats'], near_far, bn_batch_stats)
             sc['nb_frames'] = self.unpreprocess(x['nb_imgs'])
         sc['pad'] = self.args.pad if (self.encoding_net is not None or self.encoding_net_dy is not None) else 0
         sc['imgs'] = self.unpreprocess(imgs)

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=1024)
     ap.add_argument("--precision", type=int, default=16)
     ap.add_argument("--images", type=int, default=3)
+    ap.add_argument("--val-rays", type=int, default=None, help="args.zest_val_rays: rays per rendering launch of forward_val")
     ap.add_argument("--serial-builders", action="store_true", help="build the two encoding volumes one after the other")
     ap.add_argument("--no-conv-autotune", action="store_true",
                     help="leave torch.backends.cudnn.benchmark off (the reference's Trainer sets benchmark=True, train.py:1331: "
@@ -35,7 +36,8 @@ def main():
     H, W = 288, 512
     x = tg._batch(7, H=H, W=W)
     args = tg._args(chunk=a.chunk, precision=a.precision, N_samples=128, pad=24, batch_size=a.chunk,
-                    zest_overlap_builders=not a.serial_builders)
+                    zest_overlap_builders=not a.serial_builders,
+                    **({} if a.val_rays is None else {"zest_val_rays": a.val_rays}))
     gen = tg._generator(args)
 
     def sync():

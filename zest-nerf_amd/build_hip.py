@@ -13,7 +13,12 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libzest_hip.so")
 SOURCES = ["capi.hip", "composite.hip", "composite_bwd.hip", "encode.hip", "rays.hip", "volume_cost.hip", "losses.hip", "mlp_plan.hip", "mlp.hip", "mlp_engine.hip", "mlp_train.hip", "mlp_train16.hip",
-           "fused.hip"]
+           "mlp_train16_dw.hip", "fused.hip"]
+# per-source flags.  The engine kernels outside the fused renderer (standalone MLP, training forward, backward data and
+# finishing kernels) are built without the SLP vectorizer for the reason given at VARIANTS below (training forward
+# -5 %, data kernel -3 %, finishing -2 %); the weight-gradient kernel, a translation unit of its own, keeps it: it runs
+# twice as long without (profiles/r03_ab_train_noslp.txt)
+SOURCE_FLAGS = {"mlp_engine.hip": ["-fno-slp-vectorize"], "mlp_train16.hip": ["-fno-slp-vectorize"]}
 # fused renderer instantiations: fused_variant.hip once per (operand type, feature shape);
 # heaviest first so the pool drains evenly
 _SHAPES = [("s4d2", 4, "true", 2, "false"), ("s2d2", 2, "true", 2, "false"), ("s4d0", 4, "true", 0, "false"),
@@ -83,7 +88,7 @@ def build(force=False, extra_flags=(), tag=None, only=None):
         LIB = os.path.join(HERE, "libzest_hip_%s.so" % tag)
     os.makedirs(OBJ, exist_ok=True)
     every = [(name, "fused_variant.hip", flags) for name, flags in VARIANTS]
-    every += [(s.replace(".hip", ""), s, []) for s in SOURCES]
+    every += [(s.replace(".hip", ""), s, SOURCE_FLAGS.get(s, [])) for s in SOURCES]
     jobs = [j for j in every if not only or j[0] in only or j[1] in only]
     if force:
         for name, _, _ in jobs:

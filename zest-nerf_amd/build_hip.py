@@ -33,7 +33,12 @@ VARIANTS = [("fused_%s_%s" % (pt, tag),
              # epilogues into v_pk_mul_f32, which beside MFMAs costs more issue time than the two plain multiplies it
              # replaces (MI355X_MICROARCH.md, 'price of one filler beside MFMAs'): +1.0 % / +1.8 % on the one- / two-net
              # feature kernels, -0.7 % on the featureless one, which keeps it (profiles/r03_ab_slp_ring.txt)
-             (["-fno-slp-vectorize"] if (nts or ntd) else []))
+             (["-fno-slp-vectorize"] if (nts or ntd) else []) +
+             # the featureless single-net kernel (the headline): LLVM's max-ILP scheduling strategy, +1.3 % in three A/B
+             # pairs in bf16 (226 instead of 246 VGPRs, no scratch), +1.7 % in split fp16 (profiles/r03_ab_sched.txt); the
+             # feature kernels lose 1 % (bf16) or gain nothing (split fp16) with it, the post-RA scheduler switched off
+             # loses 1 - 3 %
+             (["-mllvm", "-amdgpu-sched-strategy=max-ilp"] if tag == "s0" else []))
             # (tried and not kept, profiles/r03_ab_mcache.txt: "-DZEST_CHUNK=8 -DZEST_SLOTS=8 -DZEST_AHEAD=4
             # -DZEST_MCACHE_JB=5" for the 16-bit kernels with two feature k-tiles - a 64 KiB weight ring and, in the LDS
             # that frees, 5 of the 8 row blocks of the modulation m per wave (mlp_engine.cuh): 9.7 % fewer MFMAs, +2.7 % /

@@ -34,6 +34,10 @@ VARIANTS = [("fused_%s_%s" % (pt, tag),
              # replaces (MI355X_MICROARCH.md, 'price of one filler beside MFMAs'): +1.0 % / +1.8 % on the one- / two-net
              # feature kernels, -0.7 % on the featureless one, which keeps it (profiles/r03_ab_slp_ring.txt)
              (["-fno-slp-vectorize"] if (nts or ntd) else []) +
+             # ... and with the AMDGPU-specific register-pressure trackers in the scheduler: +3.1 % (one net) / +4 % (two
+             # nets) in two A/B pairs each in bf16, nothing on the featureless kernel (profiles/r03_ab_sched.txt); the split-fp16
+             # kernels (at 256 VGPRs) answer with a few more spills and keep the default
+             (["-mllvm", "-amdgpu-use-amdgpu-trackers=1"] if ((nts or ntd) and pt != "x3") else []) +
              # the featureless single-net kernel (the headline): LLVM's max-ILP scheduling strategy, +1.3 % in three A/B
              # pairs in bf16 (226 instead of 246 VGPRs, no scratch), +1.7 % in split fp16 (profiles/r03_ab_sched.txt); the
              # feature kernels lose 1 % (bf16) or gain nothing (split fp16) with it, the post-RA scheduler switched off

@@ -43,7 +43,7 @@ def _shard_worker(rank, world, port, q):
 
     def fake_rays(imgs, depths, w2cs, c2ws, intr, nf, S, chunk=-1, idx=-1, **kw):
         ids = torch.arange(idx * chunk, min((idx + 1) * chunk, H * W), dtype=torch.float32)
-        calls.append(idx)
+        calls.append((idx, chunk))
         assert kw.get("zest_rays_only") is True
         return (ids[None, :, None, None].expand(1, -1, S, 3), ids[None, :, None].expand(1, -1, 3), None,
                 ids[None, :, None, None].expand(1, -1, S, 3), ids[None, :, None].expand(1, -1, S)) + (None,) * 6
@@ -81,7 +81,9 @@ def test_forward_val_shards_chunks_and_gathers_once():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert got[0][1] == [0, 1, 2, 3] and got[1][1] == [4, 5, 6]           # contiguous chunk runs
+    # contiguous chunk runs, merged into as few sampler / renderer calls as the sampler's (index, size) addressing
+    # allows: rank 0 renders chunks 0-3 as one chunk of 32 rays, rank 1 chunks 4-5 as chunk 2 of 16 rays, then chunk 6
+    assert got[0][1] == [(0, 32)] and got[1][1] == [(2, 16), (6, 8)]
     ids = np.arange(54, dtype=np.float32)
     for rank, _, cat, chain_bwd, maps_only in got:
         assert chain_bwd is True and maps_only is False                   # 7 toggles; the flag is restored
@@ -133,7 +135,7 @@ def test_forward_val_is_chunk_invariant(hip, precision):
     for chunk, merge in ((256, 0), (384, 0), (128, 512), (128, 384)):
         gen = _generator(_args(chunk=chunk, precision=precision, zest_val_rays=merge))
         res = gen.forward_val(x)
-        assert len(res[1]) == {(256, 0): 4, (384, 0): 3, (128, 512): 2, (128, 384): 4}[(chunk, merge)]
+        assert len(res[1]) == {(256, 0): 4, (384, 0): 3, (128, 512): 2, (128, 384): 3}[(chunk, merge)]
         assert tuple(res[0].shape) == (1, 4, 3, 32, 32)
         outs.append([torch.cat(r) for r in res[1:]])
         assert [tuple(o.shape) for o in outs[-1]] == [(1024, 3), (1024,), (1024, 3), (1024,), (1024, 3), (1024,), (1024,)]

@@ -661,16 +661,19 @@ class DyMVSNeRF_G(_Generator):
             maps_only, a.zest_maps_only = getattr(a, 'zest_maps_only', False), True
             outs = {k: [] for k in self.VAL_KEYS}
             # args.chunk bounds the reference's per-sample tensors; the fused renderer keeps nothing per sample in
-            # HBM, so neighbouring chunks go through ONE ray-sampling + ONE rendering launch (`group` chunks, at
-            # least ~16k rays: 288 x 512 x 128 in 60.7 ms per image instead of 66.3 with chunk = 1024).  Rays are
+            # HBM, so neighbouring chunks go through ONE ray-sampling + ONE rendering launch (up to `group` chunks =
+            # args.zest_val_rays rays, default one NSFF image: 288 x 512 x 128 samples are 0.6 GB of ray tensors; 60.7 ms
+            # per image against 66.3 with chunk = 1024 launches in round 2, another 0.6 ms against 16k-ray launches).  Rays are
             # independent: the rows are the same, the lists just hold fewer, longer tensors.
-            group = max(1, int(getattr(a, 'zest_val_rays', 16384)) // a.chunk)
+            group = max(1, int(getattr(a, 'zest_val_rays', 147456)) // a.chunk)
             try:
                 for _ in range(n_chunks):
                     self.chain_bwd = not self.chain_bwd          # every rank keeps the reference's alternation
                 chunk_idx = lo
                 while chunk_idx < hi:
-                    n = group if (chunk_idx % group == 0 and chunk_idx + group <= hi) else 1
+                    # the largest run of chunks that starts here, is no longer than `group` and that the ray sampler
+                    # can address as ONE chunk of n * args.chunk rays (its index must be a whole number)
+                    n = next(k for k in range(min(group, hi - chunk_idx), 0, -1) if chunk_idx % k == 0)
                     r = utils.build_rays_dy(
                         sc['imgs'], x['depths'], x['w2cs'], x['c2ws'], x['intrinsics'], x['near_fars'],
                         self.N_samples, N_rays=self.N_rays, stratified=False, pad=sc['pad'], chunk=a.chunk * n,

@@ -292,3 +292,20 @@ def test_sample_pdf_inverse_cdf_properties(hip):
     z = np.linspace(2, 6, 65, dtype=np.float32)[None]
     det = zest_utils.sample_pdf(G(z), torch.ones(1, 64, device="cuda"), 33, det=True)
     close(det[0], np.linspace(2, 6, 33), atol=1e-4, rtol=0, name="uniform weights")
+
+
+@pytest.mark.parametrize("D,H,W", [(128, 120, 176), (128, 208, 288)])       # NSFF and LLFF encoding volumes
+def test_volume_layout_change_at_full_size(hip, D, H, W):
+    """The tile transpose [8,D,H,W] <-> [H,W,D,8] at the reference's real volume sizes (86.5 / 245 MB): exact both
+    ways, and the lookup on the copy equals the lookup on a permuted view made by torch."""
+    import zest_hip
+    g = torch.Generator(device="cuda").manual_seed(D + H + W)
+    vol = torch.randn(1, 8, D, H, W, device="cuda:0", generator=g)
+    cl = zest_hip.volume_to_cl(vol)
+    assert cl.shape == (H, W, D, 8) and torch.equal(cl, vol[0].permute(2, 3, 1, 0))
+    assert torch.equal(zest_hip.volume_from_cl(cl), vol)
+    ndc = torch.rand(4096, 3, device="cuda:0", generator=g) * 1.1 - 0.05          # some samples outside the volume
+    got = zest_hip.volume_lookup(cl, ndc)
+    want = torch.nn.functional.grid_sample(vol, (ndc * 2 - 1).view(1, 1, 1, -1, 3), mode="bilinear",
+                                           padding_mode="zeros", align_corners=True)[0, :, 0, 0].t()
+    assert (got - want).abs().max().item() < 2e-5

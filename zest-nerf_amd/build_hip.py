@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libzest_hip.so")
-SOURCES = ["capi.hip", "composite.hip", "composite_bwd.hip", "encode.hip", "rays.hip", "volume_cost.hip", "losses.hip", "mlp_plan.hip", "mlp.hip", "mlp_engine.hip", "mlp_train.hip", "mlp_train16.hip",
+SOURCES = ["capi.hip", "composite.hip", "composite_bwd.hip", "encode.hip", "rays.hip", "volume_cost.hip", "costreg.hip", "losses.hip", "mlp_plan.hip", "mlp.hip", "mlp_engine.hip", "mlp_train.hip", "mlp_train16.hip",
            "mlp_train16_dw.hip", "fused.hip"]
 # per-source flags.  The engine kernels outside the fused renderer (standalone MLP, training forward, backward data and
 # finishing kernels) are built without the SLP vectorizer for the reason given at VARIANTS below (training forward

@@ -1,0 +1,390 @@
+// 3-D regularisation net of the MVS volume builder: CostRegNet, reference networks.py:1003-1059 -
+// seven 3x3x3 convolutions (three of stride 2), three stride-2 transposed convolutions, a batch norm + leaky
+// ReLU(0.01) after each (InPlaceABN, networks.py:938-960), three skip additions - on the plane-sweep cost volume,
+// without autograd (whole-image evaluation; training goes through the library convolutions, which have a backward).
+//
+// Layout: every tensor is channels-last fp32 [D][H][W][C]: the K dimension of a convolution's contraction - the 3 C
+// values of a voxel's x-window in one (dz, dy) row - is then contiguous in memory, 8 channels of a pixel are one
+// 32-byte load, and no im2col buffer exists.  A convolution writes its RAW output and the per-channel sum / sum of
+// squares of it (batch statistics); the norm + activation of a layer is applied by its CONSUMER when it loads the
+// tensor (scale and shift per channel from zest_costreg_bn: two floats per channel), so an activation tensor is
+// written once and read once per consumer.  (The library path runs, per layer: convolution, statistics pass,
+// normalisation pass, activation pass, layout transposes around the convolution - 23 ms of device time for the two
+// builders of an NSFF image, profiles/r03_builder_library_kernels.txt.)
+//
+// conv3d_mfma_kernel: v_mfma_f32_16x16x32_bf16, A = packed weights (16 output channels x 32 k), B = activations
+// (32 k x 16 voxels consecutive in x): lane (n = l & 15, g = l >> 4) supplies the 8 channels of octet 4 c + g of voxel
+// n's window and receives output channels 4 g .. 4 g + 3 of voxel n (one 16-byte store).  PASSES = 1: operands
+// rounded to bf16 (the --precision 16 path; the library runs these layers under bf16 autocast there).  PASSES = 3:
+// every operand is the pair hi = bf16(v), lo = bf16(v - hi) and a product is hi hi + hi lo + lo hi - 16 significant
+// bits, bf16's exponent range (raw cost-volume variances are unbounded).  Bound: the loads of the operands through
+// the vector L1 (a window is re-read by its neighbours), not HBM and not the MFMA pipe; see DESIGN.md.
+// deconv3d_kernel: the transposed convolutions (2 GFMA in total) in fp32 on the VALU, one output voxel per thread,
+// weights and norm constants through the scalar cache.
+#include "mlp_engine.cuh"
+
+namespace {
+
+using namespace zest;
+constexpr int BF = ZEST_PREC_BF16;
+constexpr float kSlope = 0.01f;           // InPlaceABN's leaky ReLU
+
+__device__ __forceinline__ float leaky(float v) { return fmaxf(v, kSlope * v); }
+
+struct ConvArgs {
+    const float *in, *pre;                // [Di,Hi,Wi,CIN]; [2,CIN] scale / shift of the producer's norm (PRE)
+    const uint4 *w;                       // packed A operands (zest_networks.CostRegNet._pack_conv)
+    float *out;                           // [Do,Ho,Wo,COUT] raw
+    double *stats;                        // [2,COUT] sum, sum of squares: accumulated
+    int Di, Hi, Wi, Do, Ho, Wo, n_xb, n_yg, n_tiles;
+};
+
+// eight values -> operand registers (hi [, lo])
+template <int NP>
+__device__ __forceinline__ void to_operand(const float (&v)[8], bf16x8 (&op)[NP]) {
+    uint4 h;
+    h.x = pack_pair<BF>(v[0], v[1]), h.y = pack_pair<BF>(v[2], v[3]), h.z = pack_pair<BF>(v[4], v[5]), h.w = pack_pair<BF>(v[6], v[7]);
+    op[0] = __builtin_bit_cast(bf16x8, h);
+    if constexpr (NP == 2) {
+        float r[8];
+        const unsigned hw[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const unsigned bits = (e & 1) ? (hw[e >> 1] & 0xFFFF0000u) : (hw[e >> 1] << 16);
+            r[e] = v[e] - __uint_as_float(bits);              // exact
+        }
+        uint4 l;
+        l.x = pack_pair<BF>(r[0], r[1]), l.y = pack_pair<BF>(r[2], r[3]), l.z = pack_pair<BF>(r[4], r[5]), l.w = pack_pair<BF>(r[6], r[7]);
+        op[1] = __builtin_bit_cast(bf16x8, l);
+    }
+}
+
+template <int CIN, int COUT, int STRIDE, int PASSES, bool PRE, int RT>
+__global__ __launch_bounds__(256) void conv3d_mfma_kernel(const ConvArgs a) {
+    constexpr int OPT = CIN / 8;                   // channel octets per pixel
+    constexpr int CPR = (3 * OPT + 3) / 4;         // k-chunks (of 4 octets) per (dz, dy) row of the window
+    constexpr int NT = (COUT + 15) / 16, NP = PASSES == 3 ? 2 : 1;
+    constexpr int NQ = OPT > 4 ? OPT / 4 : 1;      // sets of norm constants a lane needs (its octet's channels)
+    constexpr int IY = STRIDE * (RT - 1) + 3;      // input rows under RT output rows
+    static_assert(CIN % 8 == 0 && (!PRE || OPT == 1 || OPT == 2 || OPT == 4 || OPT == 8), "channel counts");
+    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __shared__ float red[2 * NT * 16];
+    if (threadIdx.x < 2 * NT * 16) red[threadIdx.x] = 0.0f;
+    float sc[NQ][8], sh[NQ][8];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int s = 0; s < NQ; s++) {
+            const int q = OPT > 4 ? 4 * s + g : (g & (OPT - 1));       // (4 c + g) % OPT for c of set s
+#pragma unroll
+            for (int e = 0; e < 8; e++) sc[s][e] = a.pre[8 * q + e], sh[s][e] = a.pre[CIN + 8 * q + e];
+        }
+    }
+    float ssum[NT][4], ssq[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) ssum[nt][i] = ssq[nt][i] = 0.0f;
+
+    for (int t = (int)blockIdx.x * 4 + wave; t < a.n_tiles; t += (int)gridDim.x * 4) {
+        const int xb = t % a.n_xb, r_ = t / a.n_xb, yg = r_ % a.n_yg, z = r_ / a.n_yg;
+        const int x0 = xb * 16, y0 = yg * RT;
+        const int xi0 = STRIDE * (x0 + n) - 1;                        // first pixel of this lane's voxel window
+        f32x4 acc[RT][NT];
+#pragma unroll
+        for (int ry = 0; ry < RT; ry++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc[ry][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int dz = 0; dz < 3; dz++) {
+            const int zi = STRIDE * z + dz - 1;
+            if ((unsigned)zi >= (unsigned)a.Di) continue;
+#pragma unroll
+            for (int iy = 0; iy < IY; iy++) {
+                const int yi = STRIDE * y0 - 1 + iy;
+                if ((unsigned)yi >= (unsigned)a.Hi) continue;
+                const float *row = a.in + ((size_t)zi * a.Hi + yi) * a.Wi * CIN;
+                bf16x8 act[CPR][NP];
+#pragma unroll
+                for (int c = 0; c < CPR; c++) {
+                    const int o = 4 * c + g, p = o / OPT, q = o - p * OPT, xi = xi0 + p;
+                    const bool ok = o < 3 * OPT && (unsigned)xi < (unsigned)a.Wi;
+                    const float4 *src = reinterpret_cast<const float4 *>(row + (ok ? (size_t)xi * CIN + 8 * q : 0));
+                    const float4 v0 = src[0], v1 = src[1];
+                    float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    if constexpr (PRE) {
+                        const int s = OPT > 4 ? (c & 1) : 0;
+#pragma unroll
+                        for (int e = 0; e < 8; e++) v[e] = leaky(fmaf(v[e], sc[s][e], sh[s][e]));
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; e++) v[e] = ok ? v[e] : 0.0f;
+                    to_operand<NP>(v, act[c]);
+                }
+#pragma unroll
+                for (int ry = 0; ry < RT; ry++) {
+                    const int dy = iy - STRIDE * ry;                  // compile-time after unrolling
+                    if (dy < 0 || dy > 2) continue;
+                    const uint4 *wrow = a.w + (size_t)((dz * 3 + dy) * CPR) * NT * NP * 64 + lane;
+#pragma unroll
+                    for (int c = 0; c < CPR; c++)
+#pragma unroll
+                        for (int nt = 0; nt < NT; nt++) {
+                            const uint4 *wp = wrow + (size_t)(c * NT + nt) * NP * 64;
+                            const bf16x8 wh = __builtin_bit_cast(bf16x8, wp[0]);
+                            acc[ry][nt] = mfma16<BF>(wh, act[c][0], acc[ry][nt]);
+                            if constexpr (NP == 2) {
+                                const bf16x8 wl = __builtin_bit_cast(bf16x8, wp[64]);
+                                acc[ry][nt] = mfma16<BF>(wh, act[c][1], acc[ry][nt]);
+                                acc[ry][nt] = mfma16<BF>(wl, act[c][0], acc[ry][nt]);
+                            }
+                        }
+                }
+            }
+        }
+        const int x = x0 + n;
+#pragma unroll
+        for (int ry = 0; ry < RT; ry++) {
+            const int y = y0 + ry;
+            if (y >= a.Ho || x >= a.Wo) continue;
+            float *dst = a.out + (((size_t)z * a.Ho + y) * a.Wo + x) * COUT;
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+                if (nt * 16 + 4 * g >= COUT) continue;
+                const f32x4 v = acc[ry][nt];
+                *reinterpret_cast<float4 *>(dst + nt * 16 + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+                for (int i = 0; i < 4; i++) ssum[nt][i] += v[i], ssq[nt][i] = fmaf(v[i], v[i], ssq[nt][i]);
+            }
+        }
+    }
+    // statistics: the 16 voxel lanes of a group, then the workgroup's waves through LDS, then one fp64 atomic per
+    // channel and workgroup
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float s = ssum[nt][i], q = ssq[nt][i];
+#pragma unroll
+            for (int m = 8; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64), q += __shfl_xor(q, m, 64);
+            if (n == 0) atomicAdd(&red[nt * 16 + 4 * g + i], s), atomicAdd(&red[NT * 16 + nt * 16 + 4 * g + i], q);
+        }
+    __syncthreads();
+    if (threadIdx.x < 2 * NT * 16) {
+        const int which = threadIdx.x / (NT * 16), c = threadIdx.x % (NT * 16);
+        if (c < COUT) atomicAdd(&a.stats[which * COUT + c], (double)red[threadIdx.x]);
+    }
+}
+
+// ---------------------------------------------------------------------------- transposed convolution
+// ConvTranspose3d(k 3, stride 2, padding 1, output_padding 1): out[o] = sum_k in[i] w[k] over o = 2 i - 1 + k.  Per
+// dimension an even output has the single tap k = 1 (i = o / 2), an odd one k = 2 (i = (o - 1) / 2) and k = 0
+// (i = (o + 1) / 2): the eight parity classes of the output lattice (blockIdx.y) have 1 .. 8 taps, and the threads
+// of a class walk its sub-lattice, which has the input's shape.  The input is act(norm(in0)) [+ act(norm(in1))] (the
+// U-Net's skip addition happens here, on load).
+struct DeconvArgs {
+    const float *in0, *pre0, *in1, *pre1;   // [Di,Hi,Wi,CIN] raw, [2,CIN] each
+    const float *w;                         // [27][CIN][COUT]
+    float *out;                             // [2Di,2Hi,2Wi,COUT] raw
+    double *stats;
+    int Di, Hi, Wi;
+};
+
+template <int CIN, int COUT, bool IN2>
+__global__ __launch_bounds__(256) void deconv3d_kernel(const DeconvArgs a) {
+    const int cls = blockIdx.y, pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
+    const int nsub = a.Di * a.Hi * a.Wi;
+    __shared__ float red[2 * COUT];
+    if (threadIdx.x < 2 * COUT) red[threadIdx.x] = 0.0f;
+    float ssum[COUT], ssq[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; co++) ssum[co] = ssq[co] = 0.0f;
+    for (int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x); idx < nsub; idx += (int)(gridDim.x * blockDim.x)) {
+        const int xi = idx % a.Wi, r_ = idx / a.Wi, yi = r_ % a.Hi, zi = r_ / a.Hi;
+        float acc[COUT];
+#pragma unroll
+        for (int co = 0; co < COUT; co++) acc[co] = 0.0f;
+        for (int tz = 0; tz <= pz; tz++) {
+            const int kz = pz ? (tz ? 0 : 2) : 1, iz = zi + (tz ? 1 : 0);
+            for (int ty = 0; ty <= py; ty++) {
+                const int ky = py ? (ty ? 0 : 2) : 1, iy = yi + (ty ? 1 : 0);
+                for (int tx = 0; tx <= px; tx++) {
+                    const int kx = px ? (tx ? 0 : 2) : 1, ix = xi + (tx ? 1 : 0);
+                    if (iz >= a.Di || iy >= a.Hi || ix >= a.Wi) continue;
+                    const int tap = (kz * 3 + ky) * 3 + kx;
+                    const size_t off = (((size_t)iz * a.Hi + iy) * a.Wi + ix) * CIN;
+                    const float *wt = a.w + (size_t)tap * CIN * COUT;
+                    for (int c8 = 0; c8 < CIN / 8; c8++) {
+                        const float4 u0 = *reinterpret_cast<const float4 *>(a.in0 + off + 8 * c8);
+                        const float4 u1 = *reinterpret_cast<const float4 *>(a.in0 + off + 8 * c8 + 4);
+                        float v[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+#pragma unroll
+                        for (int e = 0; e < 8; e++) v[e] = leaky(fmaf(v[e], a.pre0[8 * c8 + e], a.pre0[CIN + 8 * c8 + e]));
+                        if constexpr (IN2) {
+                            const float4 t0 = *reinterpret_cast<const float4 *>(a.in1 + off + 8 * c8);
+                            const float4 t1 = *reinterpret_cast<const float4 *>(a.in1 + off + 8 * c8 + 4);
+                            const float s[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+                            for (int e = 0; e < 8; e++) v[e] += leaky(fmaf(s[e], a.pre1[8 * c8 + e], a.pre1[CIN + 8 * c8 + e]));
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; e++)
+#pragma unroll
+                            for (int co = 0; co < COUT; co++) acc[co] = fmaf(v[e], wt[(8 * c8 + e) * COUT + co], acc[co]);
+                    }
+                }
+            }
+        }
+        float *dst = a.out + ((((size_t)(2 * zi + pz)) * (2 * a.Hi) + (2 * yi + py)) * (2 * a.Wi) + (2 * xi + px)) * COUT;
+#pragma unroll
+        for (int co = 0; co < COUT; co += 4)
+            *reinterpret_cast<float4 *>(dst + co) = make_float4(acc[co], acc[co + 1], acc[co + 2], acc[co + 3]);
+#pragma unroll
+        for (int co = 0; co < COUT; co++) ssum[co] += acc[co], ssq[co] = fmaf(acc[co], acc[co], ssq[co]);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int co = 0; co < COUT; co++) {
+        const float s = wave_sum(ssum[co]), q = wave_sum(ssq[co]);
+        if (lane == 0) atomicAdd(&red[co], s), atomicAdd(&red[COUT + co], q);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * COUT) atomicAdd(&a.stats[threadIdx.x], (double)red[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------- batch norm constants
+// scale = gamma / sqrt(var + eps), shift = beta - mean scale of one layer, from the batch statistics of its raw
+// output (training-mode norm: the reference validates with batch statistics, networks.py:629, 644; the running
+// estimates are updated as nn.BatchNorm does: momentum, unbiased variance, the step counter) or from the running ones.
+__global__ void bn_constants_kernel(const double *__restrict__ stats, int C, double count, const float *__restrict__ gamma,
+                                    const float *__restrict__ beta, float eps, int batch_stats, float *running_mean,
+                                    float *running_var, float momentum, long long *steps, float *__restrict__ pre) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    float mean, var;
+    if (batch_stats) {
+        const double m = stats[c] / count;
+        double v = stats[C + c] / count - m * m;
+        v = v > 0.0 ? v : 0.0;
+        mean = (float)m, var = (float)v;
+        if (running_mean) {
+            running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean;
+            running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)(v * (count / (count > 1.0 ? count - 1.0 : 1.0)));
+            if (c == 0 && steps) *steps += 1;
+        }
+    } else {
+        mean = running_mean[c], var = running_var[c];
+    }
+    const float scale = (gamma ? gamma[c] : 1.0f) / sqrtf(var + eps);
+    pre[c] = scale, pre[C + c] = (beta ? beta[c] : 0.0f) - mean * scale;
+}
+
+// encoding volume = act(norm(a)) + act(norm(b)) (the last skip addition), [D,H,W,8] -> the reference's [8,D,H,W]
+__global__ __launch_bounds__(256) void costreg_out_kernel(const float4 *__restrict__ ra, const float *__restrict__ pa,
+                                                          const float4 *__restrict__ rb, const float *__restrict__ pb,
+                                                          long long nvox, float *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nvox) return;
+    const float4 a0 = ra[2 * i], a1 = ra[2 * i + 1], b0 = rb[2 * i], b1 = rb[2 * i + 1];
+    const float va[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, vb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+    for (int c = 0; c < 8; c++)
+        out[(size_t)c * nvox + i] = leaky(fmaf(va[c], pa[c], pa[8 + c])) + leaky(fmaf(vb[c], pb[c], pb[8 + c]));
+}
+
+template <int CIN, int COUT, int STRIDE, bool PRE>
+int launch_conv(const ConvArgs &a0, int passes, hipStream_t st) {
+    ConvArgs a = a0;
+    const long long rows = (long long)a.Do * a.Ho * ((a.Wo + 15) / 16);
+    // small levels: one row per wave so that the tiles still cover the chip
+    const bool small = rows < 8192;
+    const int RT = small ? 1 : 4;
+    a.n_xb = (a.Wo + 15) / 16, a.n_yg = (a.Ho + RT - 1) / RT, a.n_tiles = a.Do * a.n_yg * a.n_xb;
+    const int grid = a.n_tiles < 4096 ? (a.n_tiles + 3) / 4 : 1024;
+#define ZEST_CONV(P, R) hipLaunchKernelGGL((conv3d_mfma_kernel<CIN, COUT, STRIDE, P, PRE, R>), dim3(grid), dim3(256), 0, st, a)
+    if (passes == 1) { if (small) ZEST_CONV(1, 1); else ZEST_CONV(1, 4); }
+    else { if (small) ZEST_CONV(3, 1); else ZEST_CONV(3, 4); }
+#undef ZEST_CONV
+    return 0;
+}
+
+}  // namespace
+
+extern "C" size_t zest_costreg_packed_bytes(int cin_pad, int cout, int passes) {
+    const int opt = cin_pad / 8, cpr = (3 * opt + 3) / 4, nt = (cout + 15) / 16;
+    return (size_t)9 * cpr * nt * (passes == 3 ? 2 : 1) * 1024;
+}
+
+extern "C" int zest_costreg_conv_fwd(const float *in, const float *pre, const void *w_packed, int cin, int cout, int stride,
+                                     int passes, int Di, int Hi, int Wi, float *out, double *stats, void *stream) {
+    ZEST_CHECK_ARG(in && w_packed && out && stats, "zest_costreg_conv_fwd: null pointer");
+    ZEST_CHECK_ARG(((uintptr_t)in | (uintptr_t)out | (uintptr_t)w_packed) % 16 == 0, "zest_costreg_conv_fwd: pointers must be 16-byte aligned");
+    ZEST_CHECK_ARG((stride == 1 || stride == 2) && (passes == 1 || passes == 3), "zest_costreg_conv_fwd: stride %d, passes %d", stride, passes);
+    ZEST_CHECK_ARG(Di >= 1 && Hi >= 1 && Wi >= 1 && (long long)Di * Hi * Wi * cin < (1ll << 31), "zest_costreg_conv_fwd: bad shape");
+    ConvArgs a{};
+    a.in = in, a.pre = pre, a.w = (const uint4 *)w_packed, a.out = out, a.stats = stats;
+    a.Di = Di, a.Hi = Hi, a.Wi = Wi;
+    a.Do = (Di - 1) / stride + 1, a.Ho = (Hi - 1) / stride + 1, a.Wo = (Wi - 1) / stride + 1;
+    const hipStream_t st = (hipStream_t)stream;
+    const int key = cin * 1000 + cout * 10 + stride;
+    ZEST_CHECK_ARG(pre || key == 48081, "zest_costreg_conv_fwd: only the first layer (48 -> 8) reads an un-normalised input");
+    switch (key) {          // the layers of CostRegNet (reference networks.py:1007-1013)
+    case 48081: launch_conv<48, 8, 1, false>(a, passes, st); break;       // conv0 (41 channels, padded)
+    case 8162: launch_conv<8, 16, 2, true>(a, passes, st); break;         // conv1
+    case 16161: launch_conv<16, 16, 1, true>(a, passes, st); break;       // conv2
+    case 16322: launch_conv<16, 32, 2, true>(a, passes, st); break;       // conv3
+    case 32321: launch_conv<32, 32, 1, true>(a, passes, st); break;       // conv4
+    case 32642: launch_conv<32, 64, 2, true>(a, passes, st); break;       // conv5
+    case 64641: launch_conv<64, 64, 1, true>(a, passes, st); break;       // conv6
+    default:
+        zest_set_error("zest_costreg_conv_fwd: no kernel for %d -> %d channels at stride %d", cin, cout, stride);
+        return (int)hipErrorInvalidValue;
+    }
+    ZEST_RETURN_LAUNCH("zest_costreg_conv_fwd");
+}
+
+extern "C" int zest_costreg_deconv_fwd(const float *in0, const float *pre0, const float *in1, const float *pre1,
+                                       const float *w, int cin, int cout, int Di, int Hi, int Wi, float *out,
+                                       double *stats, void *stream) {
+    ZEST_CHECK_ARG(in0 && pre0 && w && out && stats && (!in1 || pre1), "zest_costreg_deconv_fwd: null pointer");
+    ZEST_CHECK_ARG(((uintptr_t)in0 | (uintptr_t)in1 | (uintptr_t)out) % 16 == 0, "zest_costreg_deconv_fwd: pointers must be 16-byte aligned");
+    ZEST_CHECK_ARG(Di >= 1 && Hi >= 1 && Wi >= 1 && (long long)Di * Hi * Wi * 8 * cout < (1ll << 31), "zest_costreg_deconv_fwd: bad shape");
+    DeconvArgs a{in0, pre0, in1, pre1, w, out, stats, Di, Hi, Wi};
+    const int nsub = Di * Hi * Wi;
+    const dim3 grid(nsub < 256 * 512 ? zest_div_up(nsub, 256) : 512, 8), block(256);
+    const hipStream_t st = (hipStream_t)stream;
+    const int key = cin * 100 + cout;
+#define ZEST_DECONV(CI, CO)                                                                         \
+    if (in1) hipLaunchKernelGGL((deconv3d_kernel<CI, CO, true>), grid, block, 0, st, a);           \
+    else hipLaunchKernelGGL((deconv3d_kernel<CI, CO, false>), grid, block, 0, st, a)
+    if (key == 6432) { ZEST_DECONV(64, 32); }            // conv7
+    else if (key == 3216) { ZEST_DECONV(32, 16); }       // conv9
+    else if (key == 1608) { ZEST_DECONV(16, 8); }        // conv11
+    else {
+        zest_set_error("zest_costreg_deconv_fwd: no kernel for %d -> %d channels", cin, cout);
+        return (int)hipErrorInvalidValue;
+    }
+#undef ZEST_DECONV
+    ZEST_RETURN_LAUNCH("zest_costreg_deconv_fwd");
+}
+
+extern "C" int zest_costreg_bn(const double *stats, int C, long long count, const float *gamma, const float *beta, float eps,
+                               int batch_stats, float *running_mean, float *running_var, float momentum,
+                               long long *steps, float *pre, void *stream) {
+    ZEST_CHECK_ARG(pre && C >= 1 && C <= 256 && count >= 1, "zest_costreg_bn: bad argument");
+    ZEST_CHECK_ARG(batch_stats ? stats != nullptr : (running_mean && running_var), "zest_costreg_bn: statistics missing");
+    hipLaunchKernelGGL(bn_constants_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stats, C, (double)count, gamma, beta,
+                       eps, batch_stats, running_mean, running_var, momentum, steps, pre);
+    ZEST_RETURN_LAUNCH("zest_costreg_bn");
+}
+
+extern "C" int zest_costreg_out(const float *raw_a, const float *pre_a, const float *raw_b, const float *pre_b, int D,
+                                int H, int W, float *volume, void *stream) {
+    ZEST_CHECK_ARG(raw_a && pre_a && raw_b && pre_b && volume, "zest_costreg_out: null pointer");
+    const long long nvox = (long long)D * H * W;
+    ZEST_CHECK_ARG(nvox >= 1 && nvox < (1ll << 31), "zest_costreg_out: bad shape");
+    hipLaunchKernelGGL(costreg_out_kernel, dim3(zest_div_up(nvox, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4 *)raw_a, pre_a, (const float4 *)raw_b, pre_b, nvox, volume);
+    ZEST_RETURN_LAUNCH("zest_costreg_out");
+}

@@ -85,6 +85,7 @@ __global__ void nchw_to_nhwc_kernel(const float *__restrict__ in, int N, int C, 
 // bytes back to back.  (Round 1 transposed them through a 12 KB LDS tile into 256-byte stores; the tile
 // held the CU to 9 one-wave workgroups, and this kernel is bound by issue latency, not by either stream.)
 constexpr int kMaxViews = 8;
+constexpr int kClChannels = 48;        // channels of the channels-last cost volume (3 V + 32 = 41 for V = 3, padded to octets)
 constexpr int kRowStride = 66;      // row stride (floats) of the backward kernel's LDS transpose tile
 
 // Output path.  ZEST_SWEEP_TILE=1 (default): the 4V + 32 values of the 64 voxels are transposed through a 12 KB LDS
@@ -105,7 +106,7 @@ template <int VT>                   // VT > 0: compile-time view count (loops un
 __global__ __launch_bounds__(64) void volume_cost_tile_kernel(
     const float4 *__restrict__ feats, const float4 *__restrict__ imgs, const float *__restrict__ proj,
     const float *__restrict__ depth, int V_rt, int D, int H, int W, int pad, float *__restrict__ img_feat,
-    float *__restrict__ in_masks) {
+    float *__restrict__ in_masks, float *__restrict__ cl_out) {
     const int V = VT > 0 ? VT : V_rt;
     constexpr int VM = VT > 0 ? VT : kMaxViews;
     __shared__ float tile[(4 * VM + kC) * kTileStride];         // [rows][kTileStride]
@@ -242,6 +243,17 @@ __global__ __launch_bounds__(64) void volume_cost_tile_kernel(
   }
 }
 #else
+    if (cl_out) {
+        // channels-last for the HIP regularisation net (costreg.hip): [voxel][kClChannels], the 3 V + 32 values of a
+        // voxel followed by zeros; the workgroup's 64 voxels are 64 * kClChannels consecutive floats
+        const int live = (int)(nvox - base < 64 ? nvox - base : 64);
+        float *dst = cl_out + (size_t)base * kClChannels;
+        for (int k = 0; k < kClChannels; k++) {
+            const int e = k * 64 + lane, v = e / kClChannels, ch = e - v * kClChannels;
+            if (v < live) __builtin_nontemporal_store(ch < 3 * V + kC ? tile[ch * kTileStride + v] : 0.0f, dst + e);
+        }
+        return;
+    }
     const long long idx = base + lane;
     if (idx < nvox) {
     for (int r = 0; r < 3 * V + kC; r++) {
@@ -264,7 +276,7 @@ __attribute__((amdgpu_waves_per_eu(ZEST_SWEEP_WAVES, ZEST_SWEEP_WAVES)))
 __global__ __launch_bounds__(64) void volume_cost_kernel(
     const float4 *__restrict__ feats, const float4 *__restrict__ imgs, const float *__restrict__ proj,
     const float *__restrict__ depth, int V_rt, int D, int H, int W, int pad, float *__restrict__ img_feat,
-    float *__restrict__ in_masks) {
+    float *__restrict__ in_masks, float *__restrict__ /* cl_out: tile variant only */) {
     const int V = VT > 0 ? VT : V_rt;
     constexpr int VM = VT > 0 ? VT : kMaxViews;
     __shared__ int4 toff[(VM - 1) * 64];                       // bilinear tap offsets / weights per source view
@@ -562,27 +574,46 @@ extern "C" int zest_nchw_to_nhwc(const float *in, int N, int C, int H, int W, fl
     ZEST_RETURN_LAUNCH("zest_nchw_to_nhwc");
 }
 
-extern "C" int zest_volume_cost_fwd(const float *feats_cl, const float *imgs_cl, const float *proj,
-                                    const float *depth, int V, int C, int D, int H, int W, int pad,
-                                    float *img_feat, float *in_masks, void *stream) {
-    ZEST_CHECK_ARG(feats_cl && imgs_cl && proj && depth && img_feat && in_masks && aligned16(feats_cl) &&
-                       aligned16(imgs_cl), "zest_volume_cost_fwd: bad pointer");
-    ZEST_CHECK_ARG(C == kC, "zest_volume_cost_fwd: %d feature channels (the FeatureNet top level has %d)", C, kC);
-    ZEST_CHECK_ARG(V >= 2 && D >= 1 && H >= 2 && W >= 2 && pad >= 0, "zest_volume_cost_fwd: bad shape");
-    ZEST_CHECK_ARG(V <= kMaxViews, "zest_volume_cost_fwd: at most %d views (LDS transpose tile), got %d", kMaxViews, V);
+// img_feat + in_masks (the reference's planes) or, cl_out given, the channels-last copy for costreg.hip alone
+static int volume_cost_launch(const char *who, const float *feats_cl, const float *imgs_cl, const float *proj,
+                              const float *depth, int V, int C, int D, int H, int W, int pad, float *img_feat,
+                              float *in_masks, float *cl_out, void *stream) {
+    ZEST_CHECK_ARG(feats_cl && imgs_cl && proj && depth && ((img_feat && in_masks) || cl_out) && aligned16(feats_cl) &&
+                       aligned16(imgs_cl), "%s: bad pointer", who);
+    ZEST_CHECK_ARG(C == kC, "%s: %d feature channels (the FeatureNet top level has %d)", who, C, kC);
+    ZEST_CHECK_ARG(V >= 2 && D >= 1 && H >= 2 && W >= 2 && pad >= 0, "%s: bad shape", who);
+    ZEST_CHECK_ARG(V <= kMaxViews, "%s: at most %d views (LDS transpose tile), got %d", who, kMaxViews, V);
+    ZEST_CHECK_ARG(!cl_out || (3 * V + kC <= kClChannels && ZEST_SWEEP_TILE == 1),
+                   "%s: the channels-last volume holds %d channels, %d views need %d", who, kClChannels, V, 3 * V + kC);
     const long long nvox = (long long)D * (H + 2 * pad) * (W + 2 * pad);
-    ZEST_CHECK_ARG(nvox < (1ll << 31), "zest_volume_cost_fwd: %lld voxels exceed the 32-bit index range", nvox);
-    ZEST_CHECK_ARG((long long)V * H * W * 128 < (1ll << 32), "zest_volume_cost_fwd: feature maps of %d x %d x %d "
-                   "pixels exceed the 32-bit byte offsets of the gather", V, H, W);
+    ZEST_CHECK_ARG(nvox < (1ll << 31), "%s: %lld voxels exceed the 32-bit index range", who, nvox);
+    ZEST_CHECK_ARG((long long)V * H * W * 128 < (1ll << 32), "%s: feature maps of %d x %d x %d "
+                   "pixels exceed the 32-bit byte offsets of the gather", who, V, H, W);
 #define ZEST_SWEEP(VT)                                                                               \
     hipLaunchKernelGGL(volume_cost_kernel<VT>, dim3(zest_div_up(nvox, 64)), dim3(64), 0,                 \
                        (hipStream_t)stream, (const float4 *)feats_cl, (const float4 *)imgs_cl, proj, depth, \
-                       V, D, H, W, pad, img_feat, in_masks)
+                       V, D, H, W, pad, img_feat, in_masks, cl_out)
     if (V == 3) ZEST_SWEEP(3);          // the shipped configurations: reference + 2 source views
     else if (V == 4) ZEST_SWEEP(4);
     else ZEST_SWEEP(0);
 #undef ZEST_SWEEP
-    ZEST_RETURN_LAUNCH("zest_volume_cost_fwd");
+    ZEST_RETURN_LAUNCH(who);
+}
+
+extern "C" int zest_volume_cost_fwd(const float *feats_cl, const float *imgs_cl, const float *proj,
+                                    const float *depth, int V, int C, int D, int H, int W, int pad,
+                                    float *img_feat, float *in_masks, void *stream) {
+    ZEST_CHECK_ARG(img_feat && in_masks, "zest_volume_cost_fwd: bad pointer");
+    return volume_cost_launch("zest_volume_cost_fwd", feats_cl, imgs_cl, proj, depth, V, C, D, H, W, pad, img_feat,
+                              in_masks, nullptr, stream);
+}
+
+extern "C" int zest_volume_cost_cl_fwd(const float *feats_cl, const float *imgs_cl, const float *proj,
+                                       const float *depth, int V, int C, int D, int H, int W, int pad,
+                                       float *cost_cl, void *stream) {
+    ZEST_CHECK_ARG(cost_cl && aligned16(cost_cl), "zest_volume_cost_cl_fwd: bad pointer");
+    return volume_cost_launch("zest_volume_cost_cl_fwd", feats_cl, imgs_cl, proj, depth, V, C, D, H, W, pad, nullptr,
+                              nullptr, cost_cl, stream);
 }
 
 extern "C" int zest_homo_warp_fwd(const float *src, const float *proj, const float *depth,

@@ -82,6 +82,12 @@ _SIGS = {
     "zest_project_rays_bwd": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _i, _i, _vp, _vp, _vp]),
     "zest_volume_cost_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "zest_homo_warp_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "zest_volume_cost_cl_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "zest_costreg_packed_bytes": (_sz, [_i, _i, _i]),
+    "zest_costreg_conv_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "zest_costreg_deconv_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "zest_costreg_bn": (_i, [_vp, _i, C.c_longlong, _vp, _vp, _f, _i, _vp, _vp, _f, _vp, _vp, _vp]),
+    "zest_costreg_out": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "zest_volume_cost_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "zest_homo_warp_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "zest_volume_lookup_fwd": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
@@ -323,6 +329,93 @@ def volume_cost(feats, imgs_lr, proj, depth, pad=0, return_feats_cl=False):
     _check(lib().zest_volume_cost_fwd(_ptr(fcl), _ptr(icl), _ptr(proj), _ptr(depth), V, Cc, D, H, W, pad,
                                       _ptr(img_feat), _ptr(masks), _stream(feats)), "zest_volume_cost_fwd")
     return (img_feat, masks, fcl) if return_feats_cl else (img_feat, masks)
+
+
+COST_CL_CHANNELS = 48            # channels of the channels-last cost volume (41 used for V = 3)
+
+
+def volume_cost_cl(feats, imgs_lr, proj, depth, pad=0):
+    """The plane-sweep cost volume for the HIP regularisation net: [D, H+2pad, W+2pad, 48] channels-last
+    (channels 3V+32 .. 47 are zero), no masks.  Arguments as volume_cost."""
+    feats, imgs_lr = _dev(feats, "feats"), _dev(imgs_lr, "imgs")
+    proj, depth = _dev(proj, "proj_mats"), _dev(depth, "depth_values")
+    V, Cc, H, W = feats.shape
+    if tuple(imgs_lr.shape) != (V, 3, H, W) or tuple(proj.shape) != (V - 1, 3, 4) or depth.dim() != 1:
+        raise RuntimeError("zest_hip.volume_cost_cl: feats %s imgs %s proj %s depth %s"
+                           % (tuple(feats.shape), tuple(imgs_lr.shape), tuple(proj.shape), tuple(depth.shape)))
+    D, Hp, Wp = depth.shape[0], H + 2 * pad, W + 2 * pad
+    fcl, icl = nchw_to_nhwc(feats), images_to_cl(imgs_lr)
+    out = torch.empty(D, Hp, Wp, COST_CL_CHANNELS, device=feats.device, dtype=torch.float32)
+    _check(lib().zest_volume_cost_cl_fwd(_ptr(fcl), _ptr(icl), _ptr(proj), _ptr(depth), V, Cc, D, H, W, pad,
+                                         _ptr(out), _stream(feats)), "zest_volume_cost_cl_fwd")
+    return out
+
+
+def costreg_conv(x, pre, w_packed, cout, stride, passes, stats):
+    """x [D,H,W,cin] raw channels-last; pre [2,cin] or None; -> raw [Do,Ho,Wo,cout]; stats [2,cout] float64 += ."""
+    x = _dev(x, "x")
+    D, H, W, cin = x.shape
+    need = int(lib().zest_costreg_packed_bytes(cin, cout, passes))
+    if w_packed.numel() * w_packed.element_size() != need or not w_packed.is_cuda:
+        raise RuntimeError("zest_hip.costreg_conv: packed weights of %d bytes, %d -> %d channels in %d passes take %d"
+                           % (w_packed.numel() * w_packed.element_size(), cin, cout, passes, need))
+    if pre is not None and (tuple(pre.shape) != (2, cin) or pre.dtype != torch.float32 or not pre.is_contiguous()):
+        raise RuntimeError("zest_hip.costreg_conv: pre %s for %d channels" % (tuple(pre.shape), cin))
+    if tuple(stats.shape) != (2, cout) or stats.dtype != torch.float64 or not stats.is_contiguous():
+        raise RuntimeError("zest_hip.costreg_conv: stats %s %s for %d channels" % (tuple(stats.shape), stats.dtype, cout))
+    o = lambda n: (n - 1) // stride + 1
+    out = torch.empty(o(D), o(H), o(W), cout, device=x.device, dtype=torch.float32)
+    _check(lib().zest_costreg_conv_fwd(_ptr(x), _ptr(pre), _ptr(w_packed), cin, cout, stride, passes, D, H, W,
+                                       _ptr(out), _ptr(stats), _stream(x)), "zest_costreg_conv_fwd")
+    return out
+
+
+def costreg_deconv(x0, pre0, x1, pre1, w, stats):
+    """act(norm(x0)) [+ act(norm(x1))] [D,H,W,cin] -> raw [2D,2H,2W,cout]; w [27,cin,cout] fp32."""
+    x0 = _dev(x0, "x0")
+    D, H, W, cin = x0.shape
+    cout = w.shape[2]
+    x1 = _dev(x1, "x1", (D, H, W, cin))
+    for nm, t in (("pre0", pre0), ("pre1", pre1)):
+        if t is not None and (tuple(t.shape) != (2, cin) or t.dtype != torch.float32 or not t.is_contiguous()):
+            raise RuntimeError("zest_hip.costreg_deconv: %s %s for %d channels" % (nm, tuple(t.shape), cin))
+    if tuple(w.shape) != (27, cin, cout) or w.dtype != torch.float32 or not w.is_contiguous() or not w.is_cuda:
+        raise RuntimeError("zest_hip.costreg_deconv: weights %s" % (tuple(w.shape),))
+    if tuple(stats.shape) != (2, cout) or stats.dtype != torch.float64 or not stats.is_contiguous():
+        raise RuntimeError("zest_hip.costreg_deconv: stats %s %s for %d channels" % (tuple(stats.shape), stats.dtype, cout))
+    out = torch.empty(2 * D, 2 * H, 2 * W, cout, device=x0.device, dtype=torch.float32)
+    _check(lib().zest_costreg_deconv_fwd(_ptr(x0), _ptr(pre0), _ptr(x1), _ptr(pre1), _ptr(w), cin, cout, D, H, W,
+                                         _ptr(out), _ptr(stats), _stream(x0)), "zest_costreg_deconv_fwd")
+    return out
+
+
+def costreg_bn(stats, count, bn, batch_stats, pre):
+    """pre [2,C] <- scale / shift of the batch norm module `bn` (weight, bias, running_*, eps, momentum) from the
+    batch statistics `stats` [2,C] of `count` voxels (and the running estimates updated) or from the running ones."""
+    Cn = pre.shape[1]
+    track = bn.running_mean is not None
+    if not batch_stats and not track:
+        raise RuntimeError("zest_hip.costreg_bn: a norm without running statistics needs batch statistics")
+    mom = 0.1 if bn.momentum is None else float(bn.momentum)
+    _check(lib().zest_costreg_bn(_ptr(stats), Cn, int(count), _ptr(bn.weight), _ptr(bn.bias), float(bn.eps),
+                                 1 if batch_stats else 0, _ptr(bn.running_mean) if track else None,
+                                 _ptr(bn.running_var) if track else None, mom,
+                                 _ptr(bn.num_batches_tracked) if (track and batch_stats) else None, _ptr(pre),
+                                 _stream(pre)), "zest_costreg_bn")
+    return pre
+
+
+def costreg_out(raw_a, pre_a, raw_b, pre_b):
+    """act(norm(raw_a)) + act(norm(raw_b)), [D,H,W,8] each -> the encoding volume [1,8,D,H,W]."""
+    raw_a = _dev(raw_a, "raw_a")
+    D, H, W, Cn = raw_a.shape
+    raw_b = _dev(raw_b, "raw_b", (D, H, W, 8))
+    if Cn != 8 or tuple(pre_a.shape) != (2, 8) or tuple(pre_b.shape) != (2, 8):
+        raise RuntimeError("zest_hip.costreg_out: %s, %s, %s" % (tuple(raw_a.shape), tuple(pre_a.shape), tuple(pre_b.shape)))
+    out = torch.empty(1, 8, D, H, W, device=raw_a.device, dtype=torch.float32)
+    _check(lib().zest_costreg_out(_ptr(raw_a), _ptr(pre_a), _ptr(raw_b), _ptr(pre_b), D, H, W, _ptr(out),
+                                  _stream(raw_a)), "zest_costreg_out")
+    return out
 
 
 def volume_cost_bwd(feats_cl, proj, depth, pad, g_img_feat):

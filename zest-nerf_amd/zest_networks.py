@@ -423,6 +423,82 @@ class CostRegNet(nn.Module):
             nn.ConvTranspose3d(i, o, 3, padding=1, output_padding=1, stride=2, bias=False), norm_act(o))
         self.conv7, self.conv9, self.conv11 = up(64, 32), up(32, 16), up(16, 8)
 
+    # ---- HIP path, no autograd (csrc/costreg.hip): channels-last tensors, a layer's norm + activation applied by
+    # the layer that reads it, batch statistics from the convolution kernels themselves
+    _HIP_CONVS = (("conv0", 1), ("conv1", 2), ("conv2", 1), ("conv3", 2), ("conv4", 1), ("conv5", 2), ("conv6", 1))
+    _HIP_UPS = ("conv7", "conv9", "conv11")
+
+    def hip_supported(self):
+        """The HIP kernels cover the reference's layer shapes with leaky-ReLU(0.01) norms."""
+        bns = [getattr(self, n).bn for n, _ in self._HIP_CONVS] + [getattr(self, n)[1] for n in self._HIP_UPS]
+        return (self.conv0.conv.in_channels <= zest_hip.COST_CL_CHANNELS and self.conv0.conv.out_channels == 8
+                and all(isinstance(b, ActivatedBatchNorm) and b.activation == "leaky_relu"
+                        and abs(b.activation_param - 0.01) < 1e-12 for b in bns))
+
+    @staticmethod
+    def _pack_conv(w, passes):
+        """Conv3d weight [cout,cin,3,3,3] -> MFMA A operands [dz][dy][chunk][16-row tile][hi, lo][lane] x 8 bf16:
+        lane (m = l & 15, g = l >> 4) of chunk c holds output channel 16 nt + m against octet o = 4 c + g of the
+        x-window (pixel o // (cin/8), channels 8 (o % (cin/8)) ..+7), zero beyond the window / the channels."""
+        cout, cin = w.shape[:2]
+        opt = (cin + 7) // 8
+        cpr, nt, dev = (3 * opt + 3) // 4, (cout + 15) // 16, w.device
+        lane, e = torch.arange(64, device=dev), torch.arange(8, device=dev)
+        o = 4 * torch.arange(cpr, device=dev).view(cpr, 1, 1, 1) + (lane >> 4).view(1, 1, 64, 1)
+        px, ci = o // opt, 8 * (o % opt) + e.view(1, 1, 1, 8)
+        co = 16 * torch.arange(nt, device=dev).view(1, nt, 1, 1) + (lane & 15).view(1, 1, 64, 1)
+        valid = ((o < 3 * opt) & (ci < cin) & (co < cout)).expand(cpr, nt, 64, 8)
+        full = (cpr, nt, 64, 8)
+        vals = w.detach().float()[co.clamp(max=cout - 1).expand(full), ci.clamp(max=cin - 1).expand(full), :, :,
+                                  px.clamp(max=2).expand(full)]                     # [cpr,nt,64,8,dz,dy]
+        vals = (vals * valid[..., None, None]).permute(4, 5, 0, 1, 2, 3)
+        hi = vals.to(torch.bfloat16)
+        parts = [hi] if passes == 1 else [hi, (vals - hi.float()).to(torch.bfloat16)]
+        return torch.stack(parts, 4).contiguous().view(torch.int16).view(-1)       # [3,3,cpr,nt,parts,64,8]
+
+    def _hip_packs(self, passes):
+        ws = [getattr(self, n).conv.weight for n, _ in self._HIP_CONVS] + [getattr(self, n)[0].weight for n in self._HIP_UPS]
+        key = (passes,) + tuple((id(w), w._version, str(w.device)) for w in ws)
+        cache = self.__dict__.get("_zest_packs")
+        if cache is None or cache[0] != key:
+            packs = {n: self._pack_conv(getattr(self, n).conv.weight, passes) for n, _ in self._HIP_CONVS}
+            for n in self._HIP_UPS:
+                w = getattr(self, n)[0].weight.detach().float()                    # [cin,cout,3,3,3]
+                packs[n] = w.permute(2, 3, 4, 0, 1).reshape(27, w.shape[0], w.shape[1]).contiguous()
+            self.__dict__["_zest_packs"] = cache = (key, packs)
+        return cache[1]
+
+    def forward_hip(self, cost_cl, passes=3):
+        """cost_cl [D,H,W,48] channels-last (zest_hip.volume_cost_cl) -> encoding volume [1,8,D,H,W], no graph.
+        passes 3: split-bf16 operands (16 significant bits); 1: bf16 operands (the --precision 16 path).  Norms in
+        training mode use (and record) batch statistics, as the library path does."""
+        D, H, W, _ = cost_cl.shape
+        if D % 8 or H % 8 or W % 8:
+            raise RuntimeError("CostRegNet.forward_hip: volume %dx%dx%d is not a multiple of 8 per axis" % (D, H, W))
+        packs = self._hip_packs(passes)
+        bns = [getattr(self, n).bn for n, _ in self._HIP_CONVS] + [getattr(self, n)[1] for n in self._HIP_UPS]
+        chans = [b.num_features for b in bns]
+        offs = [0]
+        for c in chans:
+            offs.append(offs[-1] + 2 * c)
+        stats_all = torch.zeros(offs[-1], device=cost_cl.device, dtype=torch.float64)
+        pre_all = torch.empty(offs[-1], device=cost_cl.device, dtype=torch.float32)
+        st = [stats_all[offs[i]:offs[i + 1]].view(2, c) for i, c in enumerate(chans)]
+        pr = [pre_all[offs[i]:offs[i + 1]].view(2, c) for i, c in enumerate(chans)]
+        norm = lambda i, t: zest_hip.costreg_bn(st[i], t.numel() // chans[i], bns[i], bns[i].training, pr[i])
+        raw, x, pre = [], cost_cl, None
+        for i, (name, stride) in enumerate(self._HIP_CONVS):
+            x = zest_hip.costreg_conv(x, pre, packs[name], chans[i], stride, passes, st[i])
+            pre = norm(i, x)
+            raw.append(x)
+        up = zest_hip.costreg_deconv(raw[6], pr[6], None, None, packs["conv7"], st[7])
+        norm(7, up)
+        up = zest_hip.costreg_deconv(raw[4], pr[4], up, pr[7], packs["conv9"], st[8])
+        norm(8, up)
+        up = zest_hip.costreg_deconv(raw[2], pr[2], up, pr[8], packs["conv11"], st[9])
+        norm(9, up)
+        return zest_hip.costreg_out(raw[0], pr[0], up, pr[9])
+
     def forward(self, x):
         """-> (encoding volume, the output of every level: three on the way down, the bottom, three on the way up).
         Only the first element is on the path (the list: reference call shape, networks.py:1213-1230)."""
@@ -489,6 +565,18 @@ class MVSNet(nn.Module):
         else:
             depth_values = 1. / (1. / near * (1. - t_vals) + 1. / far * t_vals)
         depth_values = depth_values.unsqueeze(0)
+        Dp, Hp, Wp = D, feats.shape[-2] + 2 * pad, feats.shape[-1] + 2 * pad
+        if (not torch.is_grad_enabled() and imgs.is_cuda and B == 1 and 3 * V + 32 <= zest_hip.COST_CL_CHANNELS
+                and not return_color and not (Dp % 8 or Hp % 8 or Wp % 8) and getattr(self, "zest_hip_costreg", True)
+                and self.cost_reg_2.hip_supported()):
+            # whole-image evaluation: plane sweep straight into the channels-last layout of the HIP regularisation
+            # net (csrc/costreg.hip); bf16 operands under autocast (--precision 16), split-bf16 pairs otherwise
+            Hf, Wf = feats.shape[-2:]
+            imgs_lr = torch.nn.functional.interpolate(imgs.reshape(B * V, *imgs.shape[2:]), (Hf, Wf), mode="bilinear",
+                                                      align_corners=False)
+            cost_cl = zest_hip.volume_cost_cl(feats[0].float(), imgs_lr.float(), proj_mats[0, 1:], depth_values[0], pad)
+            volume_feat = self.cost_reg_2.forward_hip(cost_cl, passes=1 if torch.is_autocast_enabled() else 3)
+            return volume_feat, feats, depth_values
         cost_vol, in_masks = self.build_volume_cost(imgs, feats, proj_mats, depth_values, pad=pad)
         if return_color:
             feats = torch.cat((cost_vol[:, :V * 3].view(B, V, 3, *cost_vol.shape[2:]), in_masks.unsqueeze(2)), dim=2)

@@ -64,21 +64,18 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(const ConvArgs a) {
     constexpr int OPT = CIN / 8;                   // channel octets per pixel
     constexpr int CPR = (3 * OPT + 3) / 4;         // k-chunks (of 4 octets) per (dz, dy) row of the window
     constexpr int NT = (COUT + 15) / 16, NP = PASSES == 3 ? 2 : 1;
-    constexpr int NQ = OPT > 4 ? OPT / 4 : 1;      // sets of norm constants a lane needs (its octet's channels)
     constexpr int IY = STRIDE * (RT - 1) + 3;      // input rows under RT output rows
+    constexpr bool WREG = 3 * CPR * NT * NP * 4 <= 128 && RT > 1;       // weights of a z-tap in registers
     static_assert(CIN % 8 == 0 && (!PRE || OPT == 1 || OPT == 2 || OPT == 4 || OPT == 8), "channel counts");
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     __shared__ float red[2 * NT * 16];
     if (threadIdx.x < 2 * NT * 16) red[threadIdx.x] = 0.0f;
-    float sc[NQ][8], sh[NQ][8];
+    float sc[8], sh[8];                            // norm constants of this lane's octet of the strip (64 % OPT == 0)
     if constexpr (PRE) {
+        const int q = lane % OPT;
 #pragma unroll
-        for (int s = 0; s < NQ; s++) {
-            const int q = OPT > 4 ? 4 * s + g : (g & (OPT - 1));       // (4 c + g) % OPT for c of set s
-#pragma unroll
-            for (int e = 0; e < 8; e++) sc[s][e] = a.pre[8 * q + e], sh[s][e] = a.pre[CIN + 8 * q + e];
-        }
+        for (int e = 0; e < 8; e++) sc[e] = a.pre[8 * q + e], sh[e] = a.pre[CIN + 8 * q + e];
     }
     float ssum[NT][4], ssq[NT][4];
 #pragma unroll
@@ -86,40 +83,106 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; i++) ssum[nt][i] = ssq[nt][i] = 0.0f;
 
+    // Strip staging.  The 3 C-wide windows of 16 neighbouring voxels overlap: the strip of input row (zi, yi) under
+    // them - SP pixels, contiguous in memory - is loaded ONCE per wave (lane i takes octet i: 2 KiB contiguous per
+    // round), normalised, rounded and split once, and left in a wave-private piece of LDS; the MFMA operand of
+    // (voxel n, octet 4 c + g) is then one 16-byte LDS read per part.  (Read per window from global memory every octet
+    // was fetched, normalised and rounded three times - and the loads were 32-byte pieces at a stride of C floats.)
+    // No barrier: the strip belongs to one wave, and a wave's LDS instructions execute in order.
+    constexpr int SP = STRIDE * 15 + 3, NO = SP * OPT, NR = (NO + 63) / 64;
+    constexpr int PSTR = OPT + 1;                   // octets per pixel in LDS: one of padding (spreads the banks)
+    constexpr int PART_BYTES = SP * PSTR * 16;
+    __shared__ __attribute__((aligned(16))) char strips[4][NP * PART_BYTES];
+    char *const strip = strips[wave];
+    float4 pf[NR][2];
+    unsigned pf_ok = 0;
+    auto fetch = [&](int zi, int yi, int x0) {      // the strip of one input row -> pf (pf_ok: inside the volume)
+        const bool row_ok = (unsigned)zi < (unsigned)a.Di && (unsigned)yi < (unsigned)a.Hi;
+        const float *base = a.in + (((size_t)(row_ok ? zi : 0) * a.Hi + (row_ok ? yi : 0)) * a.Wi) * CIN;
+        const int xs = STRIDE * x0 - 1;
+        pf_ok = 0;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int i = lane + 64 * r, xi = xs + i / OPT;
+            const bool ok = row_ok && i < NO && (unsigned)xi < (unsigned)a.Wi;
+            const float4 *src = reinterpret_cast<const float4 *>(ok ? base + ((ptrdiff_t)xs * CIN + 8 * i) : a.in);
+            pf[r][0] = src[0], pf[r][1] = src[1];            // unconditional (a select of the ADDRESS): 16-byte loads, no branches
+            pf_ok |= ok ? (1u << r) : 0u;
+        }
+    };
+    auto stage = [&]() {                            // pf -> operand halves in LDS
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int i = lane + 64 * r, sp = i / OPT, q = i - sp * OPT;
+            if (i >= NO) continue;
+            float v[8] = {pf[r][0].x, pf[r][0].y, pf[r][0].z, pf[r][0].w, pf[r][1].x, pf[r][1].y, pf[r][1].z, pf[r][1].w};
+            const bool ok = (pf_ok >> r) & 1;
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = ok ? (PRE ? leaky(fmaf(v[e], sc[e], sh[e])) : v[e]) : 0.0f;
+            bf16x8 op[NP];
+            to_operand<NP>(v, op);
+            char *dst = strip + (sp * PSTR + q) * 16;
+            *reinterpret_cast<bf16x8 *>(dst) = op[0];
+            if constexpr (NP == 2) *reinterpret_cast<bf16x8 *>(dst + PART_BYTES) = op[NP - 1];
+        }
+    };
+
     for (int t = (int)blockIdx.x * 4 + wave; t < a.n_tiles; t += (int)gridDim.x * 4) {
         const int xb = t % a.n_xb, r_ = t / a.n_xb, yg = r_ % a.n_yg, z = r_ / a.n_yg;
         const int x0 = xb * 16, y0 = yg * RT;
-        const int xi0 = STRIDE * (x0 + n) - 1;                        // first pixel of this lane's voxel window
         f32x4 acc[RT][NT];
 #pragma unroll
         for (int ry = 0; ry < RT; ry++)
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) acc[ry][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        fetch(STRIDE * z - 1, STRIDE * y0 - 1, x0);
         for (int dz = 0; dz < 3; dz++) {
             const int zi = STRIDE * z + dz - 1;
-            if ((unsigned)zi >= (unsigned)a.Di) continue;
+            const bool z_ok = (unsigned)zi < (unsigned)a.Di;
+            // the weights of this z-tap stay in registers over the tile's input rows when they fit (the three (dy)
+            // operands of a chunk are used again by every input row: read per use they were 2/3 of the kernel's L1 traffic)
+            bf16x8 wreg[WREG ? 3 : 1][WREG ? CPR : 1][WREG ? NT : 1][NP];
+            if constexpr (WREG) {
+                if (z_ok) {
+#pragma unroll
+                    for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+                        for (int c = 0; c < CPR; c++)
+#pragma unroll
+                            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                                for (int pt = 0; pt < NP; pt++)
+                                    wreg[dy][c][nt][pt] = __builtin_bit_cast(
+                                        bf16x8, a.w[((size_t)(((dz * 3 + dy) * CPR + c) * NT + nt) * NP + pt) * 64 + lane]);
+                }
+            }
 #pragma unroll
             for (int iy = 0; iy < IY; iy++) {
                 const int yi = STRIDE * y0 - 1 + iy;
-                if ((unsigned)yi >= (unsigned)a.Hi) continue;
-                const float *row = a.in + ((size_t)zi * a.Hi + yi) * a.Wi * CIN;
+                const bool row_ok = z_ok && (unsigned)yi < (unsigned)a.Hi;
+                if (row_ok) stage();
+                __builtin_amdgcn_wave_barrier();
+                // the next row's strip is requested before this one is used
+                if (iy + 1 < IY) fetch(zi, yi + 1, x0);
+                else if (dz < 2) fetch(zi + 1, STRIDE * y0 - 1, x0);
+                if (!row_ok) continue;
                 bf16x8 act[CPR][NP];
 #pragma unroll
                 for (int c = 0; c < CPR; c++) {
-                    const int o = 4 * c + g, p = o / OPT, q = o - p * OPT, xi = xi0 + p;
-                    const bool ok = o < 3 * OPT && (unsigned)xi < (unsigned)a.Wi;
-                    const float4 *src = reinterpret_cast<const float4 *>(row + (ok ? (size_t)xi * CIN + 8 * q : 0));
-                    const float4 v0 = src[0], v1 = src[1];
-                    float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                    if constexpr (PRE) {
-                        const int s = OPT > 4 ? (c & 1) : 0;
+                    const int o = 4 * c + g, p = o / OPT, q = o - p * OPT;
+                    const bool okc = o < 3 * OPT;
+                    const char *src = strip + ((okc ? STRIDE * n + p : 0) * PSTR + (okc ? q : 0)) * 16;
 #pragma unroll
-                        for (int e = 0; e < 8; e++) v[e] = leaky(fmaf(v[e], sc[s][e], sh[s][e]));
+                    for (int pt = 0; pt < NP; pt++) {
+                        bf16x8 v = *reinterpret_cast<const bf16x8 *>(src + pt * PART_BYTES);
+                        if (4 * c + 3 >= 3 * OPT) {                   // a chunk with padding octets (zero weights: keep stale LDS bits out)
+                            const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+                            v = okc ? v : z8;
+                        }
+                        act[c][pt] = v;
                     }
-#pragma unroll
-                    for (int e = 0; e < 8; e++) v[e] = ok ? v[e] : 0.0f;
-                    to_operand<NP>(v, act[c]);
                 }
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int ry = 0; ry < RT; ry++) {
                     const int dy = iy - STRIDE * ry;                  // compile-time after unrolling
@@ -130,10 +193,10 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(const ConvArgs a) {
 #pragma unroll
                         for (int nt = 0; nt < NT; nt++) {
                             const uint4 *wp = wrow + (size_t)(c * NT + nt) * NP * 64;
-                            const bf16x8 wh = __builtin_bit_cast(bf16x8, wp[0]);
+                            const bf16x8 wh = WREG ? wreg[WREG ? dy : 0][WREG ? c : 0][WREG ? nt : 0][0] : __builtin_bit_cast(bf16x8, wp[0]);
                             acc[ry][nt] = mfma16<BF>(wh, act[c][0], acc[ry][nt]);
                             if constexpr (NP == 2) {
-                                const bf16x8 wl = __builtin_bit_cast(bf16x8, wp[64]);
+                                const bf16x8 wl = WREG ? wreg[WREG ? dy : 0][WREG ? c : 0][WREG ? nt : 0][NP - 1] : __builtin_bit_cast(bf16x8, wp[64]);
                                 acc[ry][nt] = mfma16<BF>(wh, act[c][1], acc[ry][nt]);
                                 acc[ry][nt] = mfma16<BF>(wl, act[c][0], acc[ry][nt]);
                             }

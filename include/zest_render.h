@@ -167,8 +167,9 @@ int zest_homo_warp_fwd(const float *src, const float *proj, const float *depth, 
  *   bits).  out [Do,Ho,Wo,cout] raw; stats [2,cout] doubles (sum, sum of squares) are ADDED to (zero them first).
  *   Shapes: the seven layers of CostRegNet (48->8/1, 8->16/2, 16->16/1, 16->32/2, 32->32/1, 32->64/2, 64->64/1).
  * zest_costreg_deconv_fwd: ConvTranspose3d(cin -> cout, 3, stride 2, padding 1, output_padding 1, no bias) on
- *   act(norm(in0)) [+ act(norm(in1))]; w [27,cin,cout] fp32; out [2Di,2Hi,2Wi,cout] raw; stats as above.
- *   Shapes: 64->32, 32->16, 16->8.
+ *   act(norm(in0)) [+ act(norm(in1))]; w_packed: zest_costreg_deconv_packed_bytes(cin, cout, passes) bytes, the
+ *   taps of the eight output parity classes in the MFMA operand order (zest_networks.CostRegNet packs them);
+ *   out [2Di,2Hi,2Wi,cout] raw; stats and passes as above.  Shapes: 64->32, 32->16, 16->8.
  * zest_costreg_bn: pre [2,C] from the batch statistics of `count` voxels (batch_stats != 0; running_mean /
  *   running_var / steps, when given, are updated as nn.BatchNorm does in training mode) or from the running ones.
  * zest_costreg_out: encoding volume [8,D,H,W] = act(norm(raw_a)) + act(norm(raw_b)) from two [D,H,W,8] tensors. */
@@ -177,9 +178,10 @@ int zest_volume_cost_cl_fwd(const float *feats_cl, const float *imgs_cl, const f
                             int V, int C, int D, int H, int W, int pad, float *cost_cl, void *stream);
 int zest_costreg_conv_fwd(const float *in, const float *pre, const void *w_packed, int cin, int cout, int stride,
                           int passes, int Di, int Hi, int Wi, float *out, double *stats, void *stream);
+size_t zest_costreg_deconv_packed_bytes(int cin, int cout, int passes);
 int zest_costreg_deconv_fwd(const float *in0, const float *pre0, const float *in1, const float *pre1,
-                            const float *w, int cin, int cout, int Di, int Hi, int Wi, float *out,
-                            double *stats, void *stream);
+                            const void *w_packed, int cin, int cout, int passes, int Di, int Hi, int Wi,
+                            float *out, double *stats, void *stream);
 int zest_costreg_bn(const double *stats, int C, long long count, const float *gamma, const float *beta, float eps,
                     int batch_stats, float *running_mean, float *running_var, float momentum,
                     long long *steps, float *pre, void *stream);

@@ -19,8 +19,8 @@
 // every operand is the pair hi = bf16(v), lo = bf16(v - hi) and a product is hi hi + hi lo + lo hi - 16 significant
 // bits, bf16's exponent range (raw cost-volume variances are unbounded).  Bound: the loads of the operands through
 // the vector L1 (a window is re-read by its neighbours), not HBM and not the MFMA pipe; see DESIGN.md.
-// deconv3d_kernel: the transposed convolutions (2 GFMA in total) in fp32 on the VALU, one output voxel per thread,
-// weights and norm constants through the scalar cache.
+// deconv3d_mfma_kernel: the transposed convolutions as eight small convolutions (one per output parity class) over
+// the same staged input rows; see there.
 #include "mlp_engine.cuh"
 
 namespace {
@@ -241,79 +241,170 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(const ConvArgs a) {
 
 // ---------------------------------------------------------------------------- transposed convolution
 // ConvTranspose3d(k 3, stride 2, padding 1, output_padding 1): out[o] = sum_k in[i] w[k] over o = 2 i - 1 + k.  Per
-// dimension an even output has the single tap k = 1 (i = o / 2), an odd one k = 2 (i = (o - 1) / 2) and k = 0
-// (i = (o + 1) / 2): the eight parity classes of the output lattice (blockIdx.y) have 1 .. 8 taps, and the threads
-// of a class walk its sub-lattice, which has the input's shape.  The input is act(norm(in0)) [+ act(norm(in1))] (the
-// U-Net's skip addition happens here, on load).
+// dimension an even output o = 2 i has the single tap k = 1 (input i), an odd one o = 2 i + 1 the taps k = 2 (input i)
+// and k = 0 (input i + 1): the eight parity classes (pz, py, px) of the output lattice are eight small convolutions
+// over the SAME 2 x 2 x 2 input neighbourhood.  A tile is 16 consecutive voxels of the input lattice (one (z, y) row):
+// the four input rows (z + oz, y + oy) are staged as strips of 17 pixels (as above; the input is
+// act(norm(in0)) [+ act(norm(in1))] - the U-Net's skip addition happens here, on load), every class takes its taps from
+// them - 27 (tap, class) products per tile, A = the class's packed weights of that tap row, B = the window of 1
+// (px = 0) or 2 (px = 1) pixels - and writes its 16 voxels of the output (stride 2 in x).
 struct DeconvArgs {
     const float *in0, *pre0, *in1, *pre1;   // [Di,Hi,Wi,CIN] raw, [2,CIN] each
-    const float *w;                         // [27][CIN][COUT]
+    const uint4 *w;                         // [class 8][oz 2][oy 2][chunk][16-row tile][hi, lo][lane] (CostRegNet._pack_deconv)
     float *out;                             // [2Di,2Hi,2Wi,COUT] raw
     double *stats;
-    int Di, Hi, Wi;
+    int Di, Hi, Wi, n_xb, n_tiles;
 };
 
-template <int CIN, int COUT, bool IN2>
-__global__ __launch_bounds__(256) void deconv3d_kernel(const DeconvArgs a) {
-    const int cls = blockIdx.y, pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
-    const int nsub = a.Di * a.Hi * a.Wi;
-    __shared__ float red[2 * COUT];
-    if (threadIdx.x < 2 * COUT) red[threadIdx.x] = 0.0f;
-    float ssum[COUT], ssq[COUT];
+template <int CIN, int COUT, bool IN2, int PASSES>
+__global__ __launch_bounds__(256) void deconv3d_mfma_kernel(const DeconvArgs a) {
+    constexpr int OPT = CIN / 8, NT = (COUT + 15) / 16, NP = PASSES == 3 ? 2 : 1;
+    constexpr int CH1 = (OPT + 3) / 4, CH2 = (2 * OPT + 3) / 4;    // chunks that hold pixel 0 / pixels 0 and 1 of a window
+    constexpr int SP = 17, NO = SP * OPT, NR = (NO + 63) / 64, PSTR = OPT + 1, PART_BYTES = SP * PSTR * 16;
+    static_assert(OPT == 2 || OPT == 4 || OPT == 8, "channel counts");
+    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __shared__ float red[2 * NT * 16];
+    __shared__ __attribute__((aligned(16))) char strips[4][NP * PART_BYTES];
+    char *const strip = strips[wave];
+    if (threadIdx.x < 2 * NT * 16) red[threadIdx.x] = 0.0f;
+    float sc0[8], sh0[8], sc1[8], sh1[8];
+    {
+        const int q = lane % OPT;
 #pragma unroll
-    for (int co = 0; co < COUT; co++) ssum[co] = ssq[co] = 0.0f;
-    for (int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x); idx < nsub; idx += (int)(gridDim.x * blockDim.x)) {
-        const int xi = idx % a.Wi, r_ = idx / a.Wi, yi = r_ % a.Hi, zi = r_ / a.Hi;
-        float acc[COUT];
+        for (int e = 0; e < 8; e++) {
+            sc0[e] = a.pre0[8 * q + e], sh0[e] = a.pre0[CIN + 8 * q + e];
+            if constexpr (IN2) sc1[e] = a.pre1[8 * q + e], sh1[e] = a.pre1[CIN + 8 * q + e];
+        }
+    }
+    float ssum[NT][4], ssq[NT][4];
 #pragma unroll
-        for (int co = 0; co < COUT; co++) acc[co] = 0.0f;
-        for (int tz = 0; tz <= pz; tz++) {
-            const int kz = pz ? (tz ? 0 : 2) : 1, iz = zi + (tz ? 1 : 0);
-            for (int ty = 0; ty <= py; ty++) {
-                const int ky = py ? (ty ? 0 : 2) : 1, iy = yi + (ty ? 1 : 0);
-                for (int tx = 0; tx <= px; tx++) {
-                    const int kx = px ? (tx ? 0 : 2) : 1, ix = xi + (tx ? 1 : 0);
-                    if (iz >= a.Di || iy >= a.Hi || ix >= a.Wi) continue;
-                    const int tap = (kz * 3 + ky) * 3 + kx;
-                    const size_t off = (((size_t)iz * a.Hi + iy) * a.Wi + ix) * CIN;
-                    const float *wt = a.w + (size_t)tap * CIN * COUT;
-                    for (int c8 = 0; c8 < CIN / 8; c8++) {
-                        const float4 u0 = *reinterpret_cast<const float4 *>(a.in0 + off + 8 * c8);
-                        const float4 u1 = *reinterpret_cast<const float4 *>(a.in0 + off + 8 * c8 + 4);
-                        float v[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+    for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-                        for (int e = 0; e < 8; e++) v[e] = leaky(fmaf(v[e], a.pre0[8 * c8 + e], a.pre0[CIN + 8 * c8 + e]));
-                        if constexpr (IN2) {
-                            const float4 t0 = *reinterpret_cast<const float4 *>(a.in1 + off + 8 * c8);
-                            const float4 t1 = *reinterpret_cast<const float4 *>(a.in1 + off + 8 * c8 + 4);
-                            const float s[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+        for (int i = 0; i < 4; i++) ssum[nt][i] = ssq[nt][i] = 0.0f;
+    float4 pf[IN2 ? 2 : 1][NR][2];
+    unsigned pf_ok = 0;
+    auto fetch = [&](int zi, int yi, int x0) {
+        const bool row_ok = zi < a.Di && yi < a.Hi;
+        const size_t row = (((size_t)(row_ok ? zi : 0) * a.Hi + (row_ok ? yi : 0)) * a.Wi + x0) * CIN;
+        pf_ok = 0;
 #pragma unroll
-                            for (int e = 0; e < 8; e++) v[e] += leaky(fmaf(s[e], a.pre1[8 * c8 + e], a.pre1[CIN + 8 * c8 + e]));
+        for (int r = 0; r < NR; r++) {
+            const int i = lane + 64 * r;
+            const bool ok = row_ok && i < NO && x0 + i / OPT < a.Wi;
+            const size_t off = ok ? row + 8 * i : 0;
+            pf[0][r][0] = *reinterpret_cast<const float4 *>(a.in0 + off), pf[0][r][1] = *reinterpret_cast<const float4 *>(a.in0 + off + 4);
+            if constexpr (IN2)
+                pf[IN2 ? 1 : 0][r][0] = *reinterpret_cast<const float4 *>(a.in1 + off),
+                pf[IN2 ? 1 : 0][r][1] = *reinterpret_cast<const float4 *>(a.in1 + off + 4);
+            pf_ok |= ok ? (1u << r) : 0u;
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int i = lane + 64 * r, sp = i / OPT, q = i - sp * OPT;
+            if (i >= NO) continue;
+            const bool ok = (pf_ok >> r) & 1;
+            const float4 *u = pf[0][r];
+            float v[8] = {u[0].x, u[0].y, u[0].z, u[0].w, u[1].x, u[1].y, u[1].z, u[1].w};
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = leaky(fmaf(v[e], sc0[e], sh0[e]));
+            if constexpr (IN2) {
+                const float4 *t = pf[IN2 ? 1 : 0][r];
+                const float s[8] = {t[0].x, t[0].y, t[0].z, t[0].w, t[1].x, t[1].y, t[1].z, t[1].w};
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] += leaky(fmaf(s[e], sc1[e], sh1[e]));
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = ok ? v[e] : 0.0f;
+            bf16x8 op[NP];
+            to_operand<NP>(v, op);
+            char *dst = strip + (sp * PSTR + q) * 16;
+            *reinterpret_cast<bf16x8 *>(dst) = op[0];
+            if constexpr (NP == 2) *reinterpret_cast<bf16x8 *>(dst + PART_BYTES) = op[NP - 1];
+        }
+    };
+
+    for (int t = (int)blockIdx.x * 4 + wave; t < a.n_tiles; t += (int)gridDim.x * 4) {
+        const int xb = t % a.n_xb, r_ = t / a.n_xb, yi = r_ % a.Hi, zi = r_ / a.Hi;
+        const int x0 = xb * 16;
+        f32x4 acc[8][NT];
+#pragma unroll
+        for (int cls = 0; cls < 8; cls++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc[cls][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        fetch(zi, yi, x0);
+#pragma unroll 1
+        for (int step = 0; step < 4; step++) {
+            const int oz = step >> 1, oy = step & 1;
+            const bool row_ok = zi + oz < a.Di && yi + oy < a.Hi;
+            if (row_ok) stage();
+            __builtin_amdgcn_wave_barrier();
+            if (step < 3) fetch(zi + ((step + 1) >> 1), yi + ((step + 1) & 1), x0);
+            if (!row_ok) continue;
+            bf16x8 act[CH2][NP];
+#pragma unroll
+            for (int c = 0; c < CH2; c++) {
+                const int o = 4 * c + g, p = o / OPT, q = o - p * OPT;
+#pragma unroll
+                for (int pt = 0; pt < NP; pt++)
+                    act[c][pt] = *reinterpret_cast<const bf16x8 *>(strip + ((n + p) * PSTR + q) * 16 + pt * PART_BYTES);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int cls = 0; cls < 8; cls++) {
+                const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
+                if ((oz && !pz) || (oy && !py)) continue;           // this class has no tap in this input row
+                const uint4 *wrow = a.w + (size_t)(((cls * 2 + oz) * 2 + oy) * CH2) * NT * NP * 64 + lane;
+#pragma unroll
+                for (int c = 0; c < (px ? CH2 : CH1); c++)
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++) {
+                        const uint4 *wp = wrow + (size_t)(c * NT + nt) * NP * 64;
+                        const bf16x8 wh = __builtin_bit_cast(bf16x8, wp[0]);
+                        acc[cls][nt] = mfma16<BF>(wh, act[c][0], acc[cls][nt]);
+                        if constexpr (NP == 2) {
+                            const bf16x8 wl = __builtin_bit_cast(bf16x8, wp[64]);
+                            acc[cls][nt] = mfma16<BF>(wh, act[c][1], acc[cls][nt]);
+                            acc[cls][nt] = mfma16<BF>(wl, act[c][0], acc[cls][nt]);
                         }
-#pragma unroll
-                        for (int e = 0; e < 8; e++)
-#pragma unroll
-                            for (int co = 0; co < COUT; co++) acc[co] = fmaf(v[e], wt[(8 * c8 + e) * COUT + co], acc[co]);
                     }
+                // the weight loads of one class at a time (hoisted over all classes they take 500 registers at 64 -> 32)
+                if constexpr (CIN * NT * NP >= 128) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (x0 + n < a.Wi) {
+#pragma unroll
+            for (int cls = 0; cls < 8; cls++) {
+                const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
+                float *dst = a.out + ((((size_t)(2 * zi + pz)) * (2 * a.Hi) + (2 * yi + py)) * (2 * a.Wi) + (2 * (x0 + n) + px)) * COUT;
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+                    if (nt * 16 + 4 * g >= COUT) continue;
+                    const f32x4 v = acc[cls][nt];
+                    *reinterpret_cast<float4 *>(dst + nt * 16 + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) ssum[nt][i] += v[i], ssq[nt][i] = fmaf(v[i], v[i], ssq[nt][i]);
                 }
             }
         }
-        float *dst = a.out + ((((size_t)(2 * zi + pz)) * (2 * a.Hi) + (2 * yi + py)) * (2 * a.Wi) + (2 * xi + px)) * COUT;
-#pragma unroll
-        for (int co = 0; co < COUT; co += 4)
-            *reinterpret_cast<float4 *>(dst + co) = make_float4(acc[co], acc[co + 1], acc[co + 2], acc[co + 3]);
-#pragma unroll
-        for (int co = 0; co < COUT; co++) ssum[co] += acc[co], ssq[co] = fmaf(acc[co], acc[co], ssq[co]);
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int co = 0; co < COUT; co++) {
-        const float s = wave_sum(ssum[co]), q = wave_sum(ssq[co]);
-        if (lane == 0) atomicAdd(&red[co], s), atomicAdd(&red[COUT + co], q);
-    }
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float s = ssum[nt][i], q = ssq[nt][i];
+#pragma unroll
+            for (int m = 8; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64), q += __shfl_xor(q, m, 64);
+            if (n == 0) atomicAdd(&red[nt * 16 + 4 * g + i], s), atomicAdd(&red[NT * 16 + nt * 16 + 4 * g + i], q);
+        }
     __syncthreads();
-    if (threadIdx.x < 2 * COUT) atomicAdd(&a.stats[threadIdx.x], (double)red[threadIdx.x]);
+    if (threadIdx.x < 2 * NT * 16) {
+        const int which = threadIdx.x / (NT * 16), c = threadIdx.x % (NT * 16);
+        if (c < COUT) atomicAdd(&a.stats[which * COUT + c], (double)red[threadIdx.x]);
+    }
 }
 
 // ------------------------------------------------------------------------------------- batch norm constants
@@ -407,28 +498,39 @@ extern "C" int zest_costreg_conv_fwd(const float *in, const float *pre, const vo
     ZEST_RETURN_LAUNCH("zest_costreg_conv_fwd");
 }
 
+extern "C" size_t zest_costreg_deconv_packed_bytes(int cin, int cout, int passes) {
+    const int opt = cin / 8, ch2 = (2 * opt + 3) / 4, nt = (cout + 15) / 16;
+    return (size_t)8 * 2 * 2 * ch2 * nt * (passes == 3 ? 2 : 1) * 1024;
+}
+
 extern "C" int zest_costreg_deconv_fwd(const float *in0, const float *pre0, const float *in1, const float *pre1,
-                                       const float *w, int cin, int cout, int Di, int Hi, int Wi, float *out,
-                                       double *stats, void *stream) {
-    ZEST_CHECK_ARG(in0 && pre0 && w && out && stats && (!in1 || pre1), "zest_costreg_deconv_fwd: null pointer");
-    ZEST_CHECK_ARG(((uintptr_t)in0 | (uintptr_t)in1 | (uintptr_t)out) % 16 == 0, "zest_costreg_deconv_fwd: pointers must be 16-byte aligned");
+                                       const void *w_packed, int cin, int cout, int passes, int Di, int Hi, int Wi,
+                                       float *out, double *stats, void *stream) {
+    ZEST_CHECK_ARG(in0 && pre0 && w_packed && out && stats && (!in1 || pre1), "zest_costreg_deconv_fwd: null pointer");
+    ZEST_CHECK_ARG(((uintptr_t)in0 | (uintptr_t)in1 | (uintptr_t)out | (uintptr_t)w_packed) % 16 == 0,
+                   "zest_costreg_deconv_fwd: pointers must be 16-byte aligned");
+    ZEST_CHECK_ARG(passes == 1 || passes == 3, "zest_costreg_deconv_fwd: passes %d", passes);
     ZEST_CHECK_ARG(Di >= 1 && Hi >= 1 && Wi >= 1 && (long long)Di * Hi * Wi * 8 * cout < (1ll << 31), "zest_costreg_deconv_fwd: bad shape");
-    DeconvArgs a{in0, pre0, in1, pre1, w, out, stats, Di, Hi, Wi};
-    const int nsub = Di * Hi * Wi;
-    const dim3 grid(nsub < 256 * 512 ? zest_div_up(nsub, 256) : 512, 8), block(256);
+    DeconvArgs a{in0, pre0, in1, pre1, (const uint4 *)w_packed, out, stats, Di, Hi, Wi, 0, 0};
+    a.n_xb = (Wi + 15) / 16, a.n_tiles = Di * Hi * a.n_xb;
+    const dim3 grid(a.n_tiles < 4096 ? (a.n_tiles + 3) / 4 : 1024), block(256);
     const hipStream_t st = (hipStream_t)stream;
     const int key = cin * 100 + cout;
-#define ZEST_DECONV(CI, CO)                                                                         \
-    if (in1) hipLaunchKernelGGL((deconv3d_kernel<CI, CO, true>), grid, block, 0, st, a);           \
-    else hipLaunchKernelGGL((deconv3d_kernel<CI, CO, false>), grid, block, 0, st, a)
-    if (key == 6432) { ZEST_DECONV(64, 32); }            // conv7
-    else if (key == 3216) { ZEST_DECONV(32, 16); }       // conv9
-    else if (key == 1608) { ZEST_DECONV(16, 8); }        // conv11
+#define ZEST_DECONV_P(CI, CO, TWO)                                                                           \
+    if (passes == 1) hipLaunchKernelGGL((deconv3d_mfma_kernel<CI, CO, TWO, 1>), grid, block, 0, st, a);     \
+    else hipLaunchKernelGGL((deconv3d_mfma_kernel<CI, CO, TWO, 3>), grid, block, 0, st, a)
+#define ZEST_DECONV(CI, CO)                                \
+    if (in1) { ZEST_DECONV_P(CI, CO, true); }              \
+    else { ZEST_DECONV_P(CI, CO, false); }
+    if (key == 6432) { ZEST_DECONV(64, 32) }             // conv7
+    else if (key == 3216) { ZEST_DECONV(32, 16) }        // conv9
+    else if (key == 1608) { ZEST_DECONV(16, 8) }         // conv11
     else {
         zest_set_error("zest_costreg_deconv_fwd: no kernel for %d -> %d channels", cin, cout);
         return (int)hipErrorInvalidValue;
     }
 #undef ZEST_DECONV
+#undef ZEST_DECONV_P
     ZEST_RETURN_LAUNCH("zest_costreg_deconv_fwd");
 }
 

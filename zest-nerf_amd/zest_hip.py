@@ -85,7 +85,8 @@ _SIGS = {
     "zest_volume_cost_cl_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "zest_costreg_packed_bytes": (_sz, [_i, _i, _i]),
     "zest_costreg_conv_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
-    "zest_costreg_deconv_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "zest_costreg_deconv_packed_bytes": (_sz, [_i, _i, _i]),
+    "zest_costreg_deconv_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "zest_costreg_bn": (_i, [_vp, _i, C.c_longlong, _vp, _vp, _f, _i, _vp, _vp, _f, _vp, _vp, _vp]),
     "zest_costreg_out": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "zest_volume_cost_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -370,22 +371,23 @@ def costreg_conv(x, pre, w_packed, cout, stride, passes, stats):
     return out
 
 
-def costreg_deconv(x0, pre0, x1, pre1, w, stats):
-    """act(norm(x0)) [+ act(norm(x1))] [D,H,W,cin] -> raw [2D,2H,2W,cout]; w [27,cin,cout] fp32."""
+def costreg_deconv(x0, pre0, x1, pre1, w_packed, cout, passes, stats):
+    """act(norm(x0)) [+ act(norm(x1))] [D,H,W,cin] -> raw [2D,2H,2W,cout]; w_packed: CostRegNet._pack_deconv."""
     x0 = _dev(x0, "x0")
     D, H, W, cin = x0.shape
-    cout = w.shape[2]
     x1 = _dev(x1, "x1", (D, H, W, cin))
     for nm, t in (("pre0", pre0), ("pre1", pre1)):
         if t is not None and (tuple(t.shape) != (2, cin) or t.dtype != torch.float32 or not t.is_contiguous()):
             raise RuntimeError("zest_hip.costreg_deconv: %s %s for %d channels" % (nm, tuple(t.shape), cin))
-    if tuple(w.shape) != (27, cin, cout) or w.dtype != torch.float32 or not w.is_contiguous() or not w.is_cuda:
-        raise RuntimeError("zest_hip.costreg_deconv: weights %s" % (tuple(w.shape),))
+    need = int(lib().zest_costreg_deconv_packed_bytes(cin, cout, passes))
+    if w_packed.numel() * w_packed.element_size() != need or not w_packed.is_cuda:
+        raise RuntimeError("zest_hip.costreg_deconv: packed weights of %d bytes, %d -> %d channels in %d passes take %d"
+                           % (w_packed.numel() * w_packed.element_size(), cin, cout, passes, need))
     if tuple(stats.shape) != (2, cout) or stats.dtype != torch.float64 or not stats.is_contiguous():
         raise RuntimeError("zest_hip.costreg_deconv: stats %s %s for %d channels" % (tuple(stats.shape), stats.dtype, cout))
     out = torch.empty(2 * D, 2 * H, 2 * W, cout, device=x0.device, dtype=torch.float32)
-    _check(lib().zest_costreg_deconv_fwd(_ptr(x0), _ptr(pre0), _ptr(x1), _ptr(pre1), _ptr(w), cin, cout, D, H, W,
-                                         _ptr(out), _ptr(stats), _stream(x0)), "zest_costreg_deconv_fwd")
+    _check(lib().zest_costreg_deconv_fwd(_ptr(x0), _ptr(pre0), _ptr(x1), _ptr(pre1), _ptr(w_packed), cin, cout, passes,
+                                         D, H, W, _ptr(out), _ptr(stats), _stream(x0)), "zest_costreg_deconv_fwd")
     return out
 
 

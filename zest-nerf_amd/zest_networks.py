@@ -456,6 +456,35 @@ class CostRegNet(nn.Module):
         parts = [hi] if passes == 1 else [hi, (vals - hi.float()).to(torch.bfloat16)]
         return torch.stack(parts, 4).contiguous().view(torch.int16).view(-1)       # [3,3,cpr,nt,parts,64,8]
 
+    @staticmethod
+    def _pack_deconv(w, passes):
+        """ConvTranspose3d weight [cin,cout,3,3,3] -> MFMA A operands [class][oz][oy][chunk][16-row tile][hi, lo][lane]
+        x 8 bf16.  Class (pz, py, px) = parity of the output voxel; (oz, oy) = offset of the input row; per dimension
+        an even output takes tap k = 1 of input i, an odd one k = 2 of input i and k = 0 of input i + 1.  Lane
+        (m, g) of chunk c: output channel 16 nt + m against octet o = 4 c + g of the window of 1 + px pixels."""
+        cin, cout = w.shape[:2]
+        opt, nt, dev = cin // 8, (cout + 15) // 16, w.device
+        ch2 = (2 * opt + 3) // 4
+        lane, e = torch.arange(64, device=dev), torch.arange(8, device=dev)
+        o = 4 * torch.arange(ch2, device=dev).view(ch2, 1, 1, 1) + (lane >> 4).view(1, 1, 64, 1)
+        p, ci = o // opt, 8 * (o % opt) + e.view(1, 1, 1, 8)
+        co = 16 * torch.arange(nt, device=dev).view(1, nt, 1, 1) + (lane & 15).view(1, 1, 64, 1)
+        full = (ch2, nt, 64, 8)
+        wf = w.detach().float()
+        out = torch.zeros((8, 2, 2) + full, device=dev)
+        tap = lambda par, off: (2 if off == 0 else 0) if par else 1
+        for cls in range(8):
+            pz, py, px = cls >> 2, (cls >> 1) & 1, cls & 1
+            for oz in range(1 + pz):
+                for oy in range(1 + py):
+                    kx = torch.where(p == 0, tap(px, 0), tap(px, 1)).expand(full)
+                    valid = ((p <= px) & (co < cout)).expand(full)
+                    vals = wf[ci.expand(full), co.clamp(max=cout - 1).expand(full), tap(pz, oz), tap(py, oy), kx]
+                    out[cls, oz, oy] = vals * valid
+        hi = out.to(torch.bfloat16)
+        parts = [hi] if passes == 1 else [hi, (out - hi.float()).to(torch.bfloat16)]
+        return torch.stack(parts, 5).contiguous().view(torch.int16).view(-1)       # [8,2,2,ch2,nt,parts,64,8]
+
     def _hip_packs(self, passes):
         ws = [getattr(self, n).conv.weight for n, _ in self._HIP_CONVS] + [getattr(self, n)[0].weight for n in self._HIP_UPS]
         key = (passes,) + tuple((id(w), w._version, str(w.device)) for w in ws)
@@ -463,8 +492,7 @@ class CostRegNet(nn.Module):
         if cache is None or cache[0] != key:
             packs = {n: self._pack_conv(getattr(self, n).conv.weight, passes) for n, _ in self._HIP_CONVS}
             for n in self._HIP_UPS:
-                w = getattr(self, n)[0].weight.detach().float()                    # [cin,cout,3,3,3]
-                packs[n] = w.permute(2, 3, 4, 0, 1).reshape(27, w.shape[0], w.shape[1]).contiguous()
+                packs[n] = self._pack_deconv(getattr(self, n)[0].weight, passes)
             self.__dict__["_zest_packs"] = cache = (key, packs)
         return cache[1]
 
@@ -491,11 +519,11 @@ class CostRegNet(nn.Module):
             x = zest_hip.costreg_conv(x, pre, packs[name], chans[i], stride, passes, st[i])
             pre = norm(i, x)
             raw.append(x)
-        up = zest_hip.costreg_deconv(raw[6], pr[6], None, None, packs["conv7"], st[7])
+        up = zest_hip.costreg_deconv(raw[6], pr[6], None, None, packs["conv7"], chans[7], passes, st[7])
         norm(7, up)
-        up = zest_hip.costreg_deconv(raw[4], pr[4], up, pr[7], packs["conv9"], st[8])
+        up = zest_hip.costreg_deconv(raw[4], pr[4], up, pr[7], packs["conv9"], chans[8], passes, st[8])
         norm(8, up)
-        up = zest_hip.costreg_deconv(raw[2], pr[2], up, pr[8], packs["conv11"], st[9])
+        up = zest_hip.costreg_deconv(raw[2], pr[2], up, pr[8], packs["conv11"], chans[9], passes, st[9])
         norm(9, up)
         return zest_hip.costreg_out(raw[0], pr[0], up, pr[9])
 

@@ -60,7 +60,7 @@ __device__ __forceinline__ void to_operand(const float (&v)[8], bf16x8 (&op)[NP]
 }
 
 template <int CIN, int COUT, int STRIDE, int PASSES, bool PRE, int RT>
-__global__ __launch_bounds__(256) void conv3d_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvArgs a) {
     constexpr int OPT = CIN / 8;                   // channel octets per pixel
     constexpr int CPR = (3 * OPT + 3) / 4;         // k-chunks (of 4 octets) per (dz, dy) row of the window
     constexpr int NT = (COUT + 15) / 16, NP = PASSES == 3 ? 2 : 1;
@@ -94,20 +94,25 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(const ConvArgs a) {
     constexpr int PART_BYTES = SP * PSTR * 16;
     __shared__ __attribute__((aligned(16))) char strips[4][NP * PART_BYTES];
     char *const strip = strips[wave];
-    float4 pf[NR][2];
-    unsigned pf_ok = 0;
-    auto fetch = [&](int zi, int yi, int x0) {      // the strip of one input row -> pf (pf_ok: inside the volume)
-        const bool row_ok = (unsigned)zi < (unsigned)a.Di && (unsigned)yi < (unsigned)a.Hi;
+    // Rows in flight: the strip staged at step k is requested at step k - 1, or k - 2 (DEEP) where the registers allow
+    // it without losing the second wave per SIMD: the bf16 kernels (first layer 483 -> 421 us); the split-bf16 ones
+    // hold twice the weights and ran slower with it (498 -> 649 us at one wave per SIMD).
+    constexpr bool DEEP = NP == 1;
+    float4 pf[NR][2], pf2[DEEP ? NR : 1][2];
+    unsigned pf_ok = 0, pf2_ok = 0;
+    auto fetch_row = [&](int k, int z, int y0, int x0, auto &dst, unsigned &dst_ok) {   // row k of the tile's 3 IY
+        const int zi = STRIDE * z + k / IY - 1, yi = STRIDE * y0 - 1 + k % IY;
+        const bool row_ok = k < 3 * IY && (unsigned)zi < (unsigned)a.Di && (unsigned)yi < (unsigned)a.Hi;
         const float *base = a.in + (((size_t)(row_ok ? zi : 0) * a.Hi + (row_ok ? yi : 0)) * a.Wi) * CIN;
         const int xs = STRIDE * x0 - 1;
-        pf_ok = 0;
+        dst_ok = 0;
 #pragma unroll
         for (int r = 0; r < NR; r++) {
             const int i = lane + 64 * r, xi = xs + i / OPT;
             const bool ok = row_ok && i < NO && (unsigned)xi < (unsigned)a.Wi;
             const float4 *src = reinterpret_cast<const float4 *>(ok ? base + ((ptrdiff_t)xs * CIN + 8 * i) : a.in);
-            pf[r][0] = src[0], pf[r][1] = src[1];            // unconditional (a select of the ADDRESS): 16-byte loads, no branches
-            pf_ok |= ok ? (1u << r) : 0u;
+            dst[r][0] = src[0], dst[r][1] = src[1];          // unconditional (a select of the ADDRESS): 16-byte loads, no branches
+            dst_ok |= ok ? (1u << r) : 0u;
         }
     };
     auto stage = [&]() {                            // pf -> operand halves in LDS
@@ -135,7 +140,8 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(const ConvArgs a) {
         for (int ry = 0; ry < RT; ry++)
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) acc[ry][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        fetch(STRIDE * z - 1, STRIDE * y0 - 1, x0);
+        fetch_row(0, z, y0, x0, pf, pf_ok);
+        if constexpr (DEEP) fetch_row(1, z, y0, x0, pf2, pf2_ok);
         for (int dz = 0; dz < 3; dz++) {
             const int zi = STRIDE * z + dz - 1;
             const bool z_ok = (unsigned)zi < (unsigned)a.Di;
@@ -162,9 +168,14 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(const ConvArgs a) {
                 const bool row_ok = z_ok && (unsigned)yi < (unsigned)a.Hi;
                 if (row_ok) stage();
                 __builtin_amdgcn_wave_barrier();
-                // the next row's strip is requested before this one is used
-                if (iy + 1 < IY) fetch(zi, yi + 1, x0);
-                else if (dz < 2) fetch(zi + 1, STRIDE * y0 - 1, x0);
+                if constexpr (DEEP) {
+#pragma unroll
+                    for (int r = 0; r < NR; r++) pf[r][0] = pf2[r][0], pf[r][1] = pf2[r][1];
+                    pf_ok = pf2_ok;
+                    fetch_row(dz * IY + iy + 2, z, y0, x0, pf2, pf2_ok);
+                } else {
+                    fetch_row(dz * IY + iy + 1, z, y0, x0, pf, pf_ok);
+                }
                 if (!row_ok) continue;
                 bf16x8 act[CPR][NP];
 #pragma unroll

@@ -164,15 +164,18 @@ int zest_homo_warp_fwd(const float *src, const float *proj, const float *depth, 
  * zest_costreg_conv_fwd: Conv3d(cin -> cout, 3, stride, padding 1, no bias) on act(norm(in)) (pre NULL: on `in`
  *   itself - first layer only).  w_packed: zest_costreg_packed_bytes(cin, cout, passes) bytes in the MFMA operand
  *   order (zest_networks.CostRegNet packs them).  passes 1: bf16 operands; 3: split bf16 pairs (16 significant
- *   bits).  out [Do,Ho,Wo,cout] raw; stats [2,cout] doubles (sum, sum of squares) are ADDED to (zero them first).
+ *   bits).  out [Do,Ho,Wo,cout] raw; stats [zest_costreg_stat_rows(), 2, cout] doubles: every workgroup writes the
+ *   sum and sum of squares of its voxels to a row of its own (the last row holds the number of rows in use), and
+ *   zest_costreg_bn adds the rows in a fixed order - the result does not depend on the order workgroups finish in.
  *   Shapes: the seven layers of CostRegNet (48->8/1, 8->16/2, 16->16/1, 16->32/2, 32->32/1, 32->64/2, 64->64/1).
  * zest_costreg_deconv_fwd: ConvTranspose3d(cin -> cout, 3, stride 2, padding 1, output_padding 1, no bias) on
  *   act(norm(in0)) [+ act(norm(in1))]; w_packed: zest_costreg_deconv_packed_bytes(cin, cout, passes) bytes, the
  *   taps of the eight output parity classes in the MFMA operand order (zest_networks.CostRegNet packs them);
  *   out [2Di,2Hi,2Wi,cout] raw; stats and passes as above.  Shapes: 64->32, 32->16, 16->8.
- * zest_costreg_bn: pre [2,C] from the batch statistics of `count` voxels (batch_stats != 0; running_mean /
+ * zest_costreg_bn: pre [2,C] (C <= 64) from the table of batch statistics of `count` voxels (batch_stats != 0; running_mean /
  *   running_var / steps, when given, are updated as nn.BatchNorm does in training mode) or from the running ones.
  * zest_costreg_out: encoding volume [8,D,H,W] = act(norm(raw_a)) + act(norm(raw_b)) from two [D,H,W,8] tensors. */
+int zest_costreg_stat_rows(void);
 size_t zest_costreg_packed_bytes(int cin, int cout, int passes);
 int zest_volume_cost_cl_fwd(const float *feats_cl, const float *imgs_cl, const float *proj, const float *depth,
                             int V, int C, int D, int H, int W, int pad, float *cost_cl, void *stream);

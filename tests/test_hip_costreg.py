@@ -45,14 +45,16 @@ def test_conv_layer_against_library(hip, cin, cout, stride, passes, tol):
         pre = torch.stack([torch.rand(cin, device=DEV, generator=g) + 0.5, torch.randn(cin, device=DEV, generator=g) * 0.3])
         xin = torch.nn.functional.leaky_relu(xin * pre[0].view(1, -1, 1, 1, 1) + pre[1].view(1, -1, 1, 1, 1), 0.01)
     want = torch.nn.functional.conv3d(xin, w, stride=stride, padding=1)
-    stats = torch.zeros(2, cout, device=DEV, dtype=torch.float64)
+    stats = zest_hip.costreg_stats(cout, DEV)
     got = zest_hip.costreg_conv(_cl(x), pre, networks.CostRegNet._pack_conv(w, passes), cout, stride, passes, stats)
     assert tuple(got.shape) == tuple(want.shape[2:]) + (cout,)
     assert _rel(_cf(got), want) < tol
     # the batch statistics are those of the kernel's own output
     flat = got.double().reshape(-1, cout)
-    assert torch.allclose(stats[0], flat.sum(0), rtol=1e-5, atol=1e-4)
-    assert torch.allclose(stats[1], flat.square().sum(0), rtol=1e-5, atol=1e-4)
+    used = int(stats[-1, 0, 0])
+    assert 1 <= used <= stats.shape[0] - 1
+    assert torch.allclose(stats[:used].sum(0)[0], flat.sum(0), rtol=1e-5, atol=1e-4)
+    assert torch.allclose(stats[:used].sum(0)[1], flat.square().sum(0), rtol=1e-5, atol=1e-4)
 
 
 @pytest.mark.parametrize("passes,tol", [(3, 2e-4), (1, 2e-2)])
@@ -69,14 +71,16 @@ def test_deconv_layer_against_library(hip, cin, cout, two, passes, tol):
     w = torch.randn(cin, cout, 3, 3, 3, device=DEV, generator=g) / (8 * cin) ** 0.5
     xin = act(x0, p0) + (act(x1, p1) if two else 0)
     want = torch.nn.functional.conv_transpose3d(xin, w, stride=2, padding=1, output_padding=1)
-    stats = torch.zeros(2, cout, device=DEV, dtype=torch.float64)
+    stats = zest_hip.costreg_stats(cout, DEV)
     got = zest_hip.costreg_deconv(_cl(x0), p0, _cl(x1) if two else None, p1 if two else None,
                                   networks.CostRegNet._pack_deconv(w, passes), cout, passes, stats)
     assert tuple(got.shape) == (2 * D, 2 * H, 2 * W, cout)
     assert _rel(_cf(got), want) < tol
     flat = got.double().reshape(-1, cout)
-    assert torch.allclose(stats[0], flat.sum(0), rtol=1e-5, atol=1e-4)
-    assert torch.allclose(stats[1], flat.square().sum(0), rtol=1e-5, atol=1e-4)
+    used = int(stats[-1, 0, 0])
+    assert 1 <= used <= stats.shape[0] - 1
+    assert torch.allclose(stats[:used].sum(0)[0], flat.sum(0), rtol=1e-5, atol=1e-4)
+    assert torch.allclose(stats[:used].sum(0)[1], flat.square().sum(0), rtol=1e-5, atol=1e-4)
 
 
 def test_norm_constants_and_running_estimates(hip):
@@ -89,7 +93,12 @@ def test_norm_constants_and_running_estimates(hip):
     with torch.no_grad():
         bn.weight.uniform_(0.5, 1.5), bn.bias.normal_()
         ref.load_state_dict(bn.state_dict())
-    stats = torch.stack([x.double().sum(0), x.double().square().sum(0)]).contiguous()
+    stats = zest_hip.costreg_stats(C, DEV)
+    stats[:] = float("nan")                                      # rows past the count are never read
+    stats[:7] = 0
+    stats[5], stats[2] = torch.stack([x[:3000].double().sum(0), x[:3000].double().square().sum(0)]), \
+        torch.stack([x[3000:].double().sum(0), x[3000:].double().square().sum(0)])
+    stats[-1, 0, 0] = 7
     pre = torch.empty(2, C, device=DEV)
     for training in (True, False):
         bn.train(training), ref.train(training)
@@ -141,6 +150,8 @@ def test_regularisation_net_against_library(hip, training, passes, tol):
             assert int(a.num_batches_tracked) == int(b.num_batches_tracked) == (1 if training else 0)
             assert torch.allclose(a.running_mean, b.running_mean, rtol=5 * tol, atol=5 * tol)
             assert torch.allclose(a.running_var, b.running_var, rtol=5 * tol, atol=5 * tol)
+    with torch.no_grad():                                       # the batch statistics are summed in a fixed order
+        assert torch.equal(net.forward_hip(_cl(cost), passes=passes), net.forward_hip(_cl(cost), passes=passes))
     # weights are repacked when they change
     with torch.no_grad():
         net.conv2.conv.weight.mul_(1.5), ref.conv2.conv.weight.mul_(1.5)

@@ -31,11 +31,37 @@ constexpr float kSlope = 0.01f;           // InPlaceABN's leaky ReLU
 
 __device__ __forceinline__ float leaky(float v) { return fmaxf(v, kSlope * v); }
 
+// Per-channel sums of a workgroup -> its row of the partial-sum table [kStatRows + 1][2][COUT] (doubles); the first
+// value of the extra row is the number of rows in use (the kernel's grid).
+constexpr int kStatRows = 1024;           // = the largest grid of these kernels
+template <int NT, int COUT>
+__device__ __forceinline__ void stats_to_row(const float (&ssum)[NT][4], const float (&ssq)[NT][4], float (&red)[4][2 * NT * 16],
+                                             double *stats, int lane, int wave) {
+    const int n = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float s = ssum[nt][i], q = ssq[nt][i];
+#pragma unroll
+            for (int m = 8; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64), q += __shfl_xor(q, m, 64);
+            if (n == 0) red[wave][nt * 16 + 4 * g + i] = s, red[wave][NT * 16 + nt * 16 + 4 * g + i] = q;
+        }
+    __syncthreads();
+    if (threadIdx.x < 2 * NT * 16) {
+        const int which = threadIdx.x / (NT * 16), c = threadIdx.x % (NT * 16);
+        if (c < COUT)
+            stats[((size_t)blockIdx.x * 2 + which) * COUT + c] =
+                (double)red[0][threadIdx.x] + (double)red[1][threadIdx.x] + (double)red[2][threadIdx.x] + (double)red[3][threadIdx.x];
+        if (blockIdx.x == 0 && threadIdx.x == 0) stats[(size_t)kStatRows * 2 * COUT] = (double)gridDim.x;   // rows in use
+    }
+}
+
 struct ConvArgs {
     const float *in, *pre;                // [Di,Hi,Wi,CIN]; [2,CIN] scale / shift of the producer's norm (PRE)
     const uint4 *w;                       // packed A operands (zest_networks.CostRegNet._pack_conv)
     float *out;                           // [Do,Ho,Wo,COUT] raw
-    double *stats;                        // [2,COUT] sum, sum of squares: accumulated
+    double *stats;                        // [kStatRows,2,COUT] sum, sum of squares per workgroup
     int Di, Hi, Wi, Do, Ho, Wo, n_xb, n_yg, n_tiles;
 };
 
@@ -69,8 +95,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvArgs a) {
     static_assert(CIN % 8 == 0 && (!PRE || OPT == 1 || OPT == 2 || OPT == 4 || OPT == 8), "channel counts");
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    __shared__ float red[2 * NT * 16];
-    if (threadIdx.x < 2 * NT * 16) red[threadIdx.x] = 0.0f;
+    __shared__ float red[4][2 * NT * 16];
     float sc[8], sh[8];                            // norm constants of this lane's octet of the strip (64 % OPT == 0)
     if constexpr (PRE) {
         const int q = lane % OPT;
@@ -231,23 +256,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvArgs a) {
             }
         }
     }
-    // statistics: the 16 voxel lanes of a group, then the workgroup's waves through LDS, then one fp64 atomic per
-    // channel and workgroup
-    __syncthreads();
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            float s = ssum[nt][i], q = ssq[nt][i];
-#pragma unroll
-            for (int m = 8; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64), q += __shfl_xor(q, m, 64);
-            if (n == 0) atomicAdd(&red[nt * 16 + 4 * g + i], s), atomicAdd(&red[NT * 16 + nt * 16 + 4 * g + i], q);
-        }
-    __syncthreads();
-    if (threadIdx.x < 2 * NT * 16) {
-        const int which = threadIdx.x / (NT * 16), c = threadIdx.x % (NT * 16);
-        if (c < COUT) atomicAdd(&a.stats[which * COUT + c], (double)red[threadIdx.x]);
-    }
+    // statistics, in a fixed order (the image must not depend on which wave finished first): the 16 voxel lanes of a
+    // group (butterfly), the workgroup's waves in order, and this workgroup's own row of the partial sums - which
+    // zest_costreg_bn adds up in order
+    stats_to_row<NT, COUT>(ssum, ssq, red, a.stats, lane, wave);
 }
 
 // ---------------------------------------------------------------------------- transposed convolution
@@ -275,10 +287,9 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_kernel(const DeconvArgs a) 
     static_assert(OPT == 2 || OPT == 4 || OPT == 8, "channel counts");
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    __shared__ float red[2 * NT * 16];
+    __shared__ float red[4][2 * NT * 16];
     __shared__ __attribute__((aligned(16))) char strips[4][NP * PART_BYTES];
     char *const strip = strips[wave];
-    if (threadIdx.x < 2 * NT * 16) red[threadIdx.x] = 0.0f;
     float sc0[8], sh0[8], sc1[8], sh1[8];
     {
         const int q = lane % OPT;
@@ -401,36 +412,42 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_kernel(const DeconvArgs a) 
             }
         }
     }
-    __syncthreads();
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            float s = ssum[nt][i], q = ssq[nt][i];
-#pragma unroll
-            for (int m = 8; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64), q += __shfl_xor(q, m, 64);
-            if (n == 0) atomicAdd(&red[nt * 16 + 4 * g + i], s), atomicAdd(&red[NT * 16 + nt * 16 + 4 * g + i], q);
-        }
-    __syncthreads();
-    if (threadIdx.x < 2 * NT * 16) {
-        const int which = threadIdx.x / (NT * 16), c = threadIdx.x % (NT * 16);
-        if (c < COUT) atomicAdd(&a.stats[which * COUT + c], (double)red[threadIdx.x]);
-    }
+    stats_to_row<NT, COUT>(ssum, ssq, red, a.stats, lane, wave);
 }
 
 // ------------------------------------------------------------------------------------- batch norm constants
 // scale = gamma / sqrt(var + eps), shift = beta - mean scale of one layer, from the batch statistics of its raw
 // output (training-mode norm: the reference validates with batch statistics, networks.py:629, 644; the running
 // estimates are updated as nn.BatchNorm does: momentum, unbiased variance, the step counter) or from the running ones.
-__global__ void bn_constants_kernel(const double *__restrict__ stats, int C, double count, const float *__restrict__ gamma,
+__global__ __launch_bounds__(1024) void bn_constants_kernel(const double *__restrict__ stats, int C, double count, const float *__restrict__ gamma,
                                     const float *__restrict__ beta, float eps, int batch_stats, float *running_mean,
                                     float *running_var, float momentum, long long *steps, float *__restrict__ pre) {
+    __shared__ double part[1024];
+    __shared__ double total[128];
+    const int V = 2 * C, G = 1024 / V;           // V values (sum, sum of squares per channel), G row groups (C <= 64)
+    if (batch_stats) {
+        const int rows = (int)stats[(size_t)kStatRows * V];
+        const int v = threadIdx.x % V, grp = threadIdx.x / V;
+        double s = 0.0;
+        if (grp < G) {
+#pragma unroll 8
+            for (int r = grp; r < rows; r += G) s += stats[(size_t)r * V + v];           // fixed order
+        }
+        part[threadIdx.x] = s;
+        __syncthreads();
+        if (threadIdx.x < V) {
+            double t = 0.0;
+            for (int k = 0; k < G; k++) t += part[k * V + threadIdx.x];
+            total[threadIdx.x] = t;
+        }
+        __syncthreads();
+    }
     const int c = threadIdx.x;
     if (c >= C) return;
     float mean, var;
     if (batch_stats) {
-        const double m = stats[c] / count;
-        double v = stats[C + c] / count - m * m;
+        const double m = total[c] / count;
+        double v = total[C + c] / count - m * m;
         v = v > 0.0 ? v : 0.0;
         mean = (float)m, var = (float)v;
         if (running_mean) {
@@ -475,6 +492,8 @@ int launch_conv(const ConvArgs &a0, int passes, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int zest_costreg_stat_rows(void) { return kStatRows + 1; }
 
 extern "C" size_t zest_costreg_packed_bytes(int cin_pad, int cout, int passes) {
     const int opt = cin_pad / 8, cpr = (3 * opt + 3) / 4, nt = (cout + 15) / 16;
@@ -548,9 +567,9 @@ extern "C" int zest_costreg_deconv_fwd(const float *in0, const float *pre0, cons
 extern "C" int zest_costreg_bn(const double *stats, int C, long long count, const float *gamma, const float *beta, float eps,
                                int batch_stats, float *running_mean, float *running_var, float momentum,
                                long long *steps, float *pre, void *stream) {
-    ZEST_CHECK_ARG(pre && C >= 1 && C <= 256 && count >= 1, "zest_costreg_bn: bad argument");
+    ZEST_CHECK_ARG(pre && C >= 1 && C <= 64 && count >= 1, "zest_costreg_bn: bad argument (at most 64 channels)");
     ZEST_CHECK_ARG(batch_stats ? stats != nullptr : (running_mean && running_var), "zest_costreg_bn: statistics missing");
-    hipLaunchKernelGGL(bn_constants_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stats, C, (double)count, gamma, beta,
+    hipLaunchKernelGGL(bn_constants_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, stats, C, (double)count, gamma, beta,
                        eps, batch_stats, running_mean, running_var, momentum, steps, pre);
     ZEST_RETURN_LAUNCH("zest_costreg_bn");
 }

@@ -83,6 +83,7 @@ _SIGS = {
     "zest_volume_cost_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "zest_homo_warp_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "zest_volume_cost_cl_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "zest_costreg_stat_rows": (_i, []),
     "zest_costreg_packed_bytes": (_sz, [_i, _i, _i]),
     "zest_costreg_conv_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "zest_costreg_deconv_packed_bytes": (_sz, [_i, _i, _i]),
@@ -352,8 +353,23 @@ def volume_cost_cl(feats, imgs_lr, proj, depth, pad=0):
     return out
 
 
+def costreg_stat_rows():
+    return int(lib().zest_costreg_stat_rows())
+
+
+def costreg_stats(cout, device):
+    """A table of batch statistics for one layer: [rows, 2, cout] float64 (a row per workgroup of the kernel that
+    fills it, and a last one with the number of rows in use)."""
+    return torch.empty(costreg_stat_rows(), 2, cout, device=device, dtype=torch.float64)
+
+
+def _check_stats(stats, cout, who):
+    if tuple(stats.shape) != (costreg_stat_rows(), 2, cout) or stats.dtype != torch.float64 or not stats.is_contiguous():
+        raise RuntimeError("zest_hip.%s: stats %s %s for %d channels" % (who, tuple(stats.shape), stats.dtype, cout))
+
+
 def costreg_conv(x, pre, w_packed, cout, stride, passes, stats):
-    """x [D,H,W,cin] raw channels-last; pre [2,cin] or None; -> raw [Do,Ho,Wo,cout]; stats [2,cout] float64 += ."""
+    """x [D,H,W,cin] raw channels-last; pre [2,cin] or None; -> raw [Do,Ho,Wo,cout]; stats: costreg_stats(cout)."""
     x = _dev(x, "x")
     D, H, W, cin = x.shape
     need = int(lib().zest_costreg_packed_bytes(cin, cout, passes))
@@ -362,8 +378,7 @@ def costreg_conv(x, pre, w_packed, cout, stride, passes, stats):
                            % (w_packed.numel() * w_packed.element_size(), cin, cout, passes, need))
     if pre is not None and (tuple(pre.shape) != (2, cin) or pre.dtype != torch.float32 or not pre.is_contiguous()):
         raise RuntimeError("zest_hip.costreg_conv: pre %s for %d channels" % (tuple(pre.shape), cin))
-    if tuple(stats.shape) != (2, cout) or stats.dtype != torch.float64 or not stats.is_contiguous():
-        raise RuntimeError("zest_hip.costreg_conv: stats %s %s for %d channels" % (tuple(stats.shape), stats.dtype, cout))
+    _check_stats(stats, cout, "costreg_conv")
     o = lambda n: (n - 1) // stride + 1
     out = torch.empty(o(D), o(H), o(W), cout, device=x.device, dtype=torch.float32)
     _check(lib().zest_costreg_conv_fwd(_ptr(x), _ptr(pre), _ptr(w_packed), cin, cout, stride, passes, D, H, W,
@@ -383,8 +398,7 @@ def costreg_deconv(x0, pre0, x1, pre1, w_packed, cout, passes, stats):
     if w_packed.numel() * w_packed.element_size() != need or not w_packed.is_cuda:
         raise RuntimeError("zest_hip.costreg_deconv: packed weights of %d bytes, %d -> %d channels in %d passes take %d"
                            % (w_packed.numel() * w_packed.element_size(), cin, cout, passes, need))
-    if tuple(stats.shape) != (2, cout) or stats.dtype != torch.float64 or not stats.is_contiguous():
-        raise RuntimeError("zest_hip.costreg_deconv: stats %s %s for %d channels" % (tuple(stats.shape), stats.dtype, cout))
+    _check_stats(stats, cout, "costreg_deconv")
     out = torch.empty(2 * D, 2 * H, 2 * W, cout, device=x0.device, dtype=torch.float32)
     _check(lib().zest_costreg_deconv_fwd(_ptr(x0), _ptr(pre0), _ptr(x1), _ptr(pre1), _ptr(w_packed), cin, cout, passes,
                                          D, H, W, _ptr(out), _ptr(stats), _stream(x0)), "zest_costreg_deconv_fwd")
@@ -395,6 +409,8 @@ def costreg_bn(stats, count, bn, batch_stats, pre):
     """pre [2,C] <- scale / shift of the batch norm module `bn` (weight, bias, running_*, eps, momentum) from the
     batch statistics `stats` [2,C] of `count` voxels (and the running estimates updated) or from the running ones."""
     Cn = pre.shape[1]
+    if batch_stats:
+        _check_stats(stats, Cn, "costreg_bn")
     track = bn.running_mean is not None
     if not batch_stats and not track:
         raise RuntimeError("zest_hip.costreg_bn: a norm without running statistics needs batch statistics")

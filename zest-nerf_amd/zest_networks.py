@@ -509,9 +509,10 @@ class CostRegNet(nn.Module):
         offs = [0]
         for c in chans:
             offs.append(offs[-1] + 2 * c)
-        stats_all = torch.zeros(offs[-1], device=cost_cl.device, dtype=torch.float64)
+        rows = zest_hip.costreg_stat_rows()
+        stats_all = torch.empty(rows * offs[-1], device=cost_cl.device, dtype=torch.float64)
         pre_all = torch.empty(offs[-1], device=cost_cl.device, dtype=torch.float32)
-        st = [stats_all[offs[i]:offs[i + 1]].view(2, c) for i, c in enumerate(chans)]
+        st = [stats_all[rows * offs[i]:rows * offs[i + 1]].view(rows, 2, c) for i, c in enumerate(chans)]
         pr = [pre_all[offs[i]:offs[i + 1]].view(2, c) for i, c in enumerate(chans)]
         norm = lambda i, t: zest_hip.costreg_bn(st[i], t.numel() // chans[i], bns[i], bns[i].training, pr[i])
         raw, x, pre = [], cost_cl, None

@@ -174,8 +174,15 @@ int zest_homo_warp_fwd(const float *src, const float *proj, const float *depth, 
  *   out [2Di,2Hi,2Wi,cout] raw; stats and passes as above.  Shapes: 64->32, 32->16, 16->8.
  * zest_costreg_bn: pre [2,C] (C <= 64) from the table of batch statistics of `count` voxels (batch_stats != 0; running_mean /
  *   running_var / steps, when given, are updated as nn.BatchNorm does in training mode) or from the running ones.
- * zest_costreg_out: encoding volume [8,D,H,W] = act(norm(raw_a)) + act(norm(raw_b)) from two [D,H,W,8] tensors. */
+ * zest_costreg_out: encoding volume [8,D,H,W] = act(norm(raw_a)) + act(norm(raw_b)) from two [D,H,W,8] tensors.
+ * zest_conv2d_fwd: the same kernel on a batch of N images [N,H,W,cin] channels-last - Conv2d(cin -> cout, k, stride,
+ *   padding k/2, no bias) on act(norm(in)) (pre NULL: on `in` itself - first layer only), the layers of FeatureNet
+ *   (reference networks.py:962-1001): 8->8 k3 (3 input channels padded to 8), 8->16 k5/2, 16->16 k3, 16->32 k5/2,
+ *   32->32 k3.  w_packed: zest_conv2d_packed_bytes(cin, cout, k, passes) bytes; out, stats, passes as above. */
 int zest_costreg_stat_rows(void);
+size_t zest_conv2d_packed_bytes(int cin, int cout, int k, int passes);
+int zest_conv2d_fwd(const float *in, const float *pre, const void *w_packed, int cin, int cout, int k, int stride,
+                    int passes, int N, int Hi, int Wi, float *out, double *stats, void *stream);
 size_t zest_costreg_packed_bytes(int cin, int cout, int passes);
 int zest_volume_cost_cl_fwd(const float *feats_cl, const float *imgs_cl, const float *proj, const float *depth,
                             int V, int C, int D, int H, int W, int pad, float *cost_cl, void *stream);

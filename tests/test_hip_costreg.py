@@ -83,6 +83,56 @@ def test_deconv_layer_against_library(hip, cin, cout, two, passes, tol):
     assert torch.allclose(stats[:used].sum(0)[1], flat.square().sum(0), rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("passes,tol", [(3, 2e-4), (1, 2e-2)])
+@pytest.mark.parametrize("cin,cout,k,stride", [(3, 8, 3, 1), (8, 8, 3, 1), (8, 16, 5, 2), (16, 16, 3, 1), (16, 32, 5, 2), (32, 32, 3, 1)])
+def test_conv2d_layer_against_library(hip, cin, cout, k, stride, passes, tol):
+    """The layers of FeatureNet: the same kernel with one-slice-deep windows over a batch of images."""
+    import zest_hip
+    import zest_networks as networks
+    g = torch.Generator(device=DEV).manual_seed(cin * 100 + cout + k)
+    N, H, W = 3, 18, 37
+    cpad = (cin + 7) // 8 * 8
+    x = torch.randn(N, cpad, H, W, device=DEV, generator=g)
+    x[:, cin:] = 0
+    w = torch.randn(cout, cin, k, k, device=DEV, generator=g) / (k * k * cin) ** 0.5
+    pre, xin = None, x[:, :cin]
+    if cin != 3:
+        pre = torch.stack([torch.rand(cin, device=DEV, generator=g) + 0.5, torch.randn(cin, device=DEV, generator=g) * 0.3])
+        xin = torch.nn.functional.leaky_relu(xin * pre[0].view(1, -1, 1, 1) + pre[1].view(1, -1, 1, 1), 0.01)
+    want = torch.nn.functional.conv2d(xin, w, stride=stride, padding=k // 2)
+    stats = zest_hip.costreg_stats(cout, DEV)
+    got = zest_hip.conv2d_cl(x.permute(0, 2, 3, 1).contiguous(), pre, networks.pack_conv_weights(w, passes), cout, k, stride,
+                             passes, stats)
+    assert tuple(got.shape) == (N,) + tuple(want.shape[2:]) + (cout,)
+    assert _rel(got.permute(0, 3, 1, 2), want) < tol
+    used = int(stats[-1, 0, 0])
+    assert torch.allclose(stats[:used].sum(0)[0], got.double().reshape(-1, cout).sum(0), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("passes,tol", [(3, 1e-3), (1, 6e-2)])
+def test_feature_pyramid_against_library(hip, training, passes, tol):
+    import zest_networks as networks
+    torch.manual_seed(5)
+    net, ref = networks.FeatureNet().to(DEV), networks.FeatureNet().to(DEV)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, networks.ActivatedBatchNorm):
+                m.weight.uniform_(0.5, 1.5), m.bias.normal_(0, 0.2), m.running_mean.normal_(0, 0.1), m.running_var.uniform_(0.5, 2)
+    ref.load_state_dict(net.state_dict())
+    net.train(training), ref.train(training)
+    imgs = torch.randn(3, 3, 40, 72, device=DEV)
+    with torch.no_grad():
+        want = ref(imgs)[0]
+        got = net.forward_hip(imgs, passes=passes)
+    assert tuple(got.shape) == (3, 10, 18, 32) and tuple(want.shape) == (3, 32, 10, 18)
+    assert _rel(got.permute(0, 3, 1, 2), want) < tol
+    for a, b in zip(net.modules(), ref.modules()):
+        if isinstance(a, networks.ActivatedBatchNorm):
+            assert int(a.num_batches_tracked) == int(b.num_batches_tracked) == (1 if training else 0)
+            assert torch.allclose(a.running_var, b.running_var, rtol=5 * tol, atol=5 * tol)
+
+
 def test_norm_constants_and_running_estimates(hip):
     import zest_hip
     import zest_networks as networks

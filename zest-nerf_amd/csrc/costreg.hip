@@ -85,13 +85,16 @@ __device__ __forceinline__ void to_operand(const float (&v)[8], bf16x8 (&op)[NP]
     }
 }
 
-template <int CIN, int COUT, int STRIDE, int PASSES, bool PRE, int RT>
+// K: taps per axis in y and x (3 or 5, padding K / 2); KD: taps in z (3, padding 1 - or 1: the slices are the images of
+// a batch, a 2-D convolution: FeatureNet, reference networks.py:962-1001; z is then not strided)
+template <int CIN, int COUT, int STRIDE, int PASSES, bool PRE, int RT, int K = 3, int KD = 3>
 __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvArgs a) {
     constexpr int OPT = CIN / 8;                   // channel octets per pixel
-    constexpr int CPR = (3 * OPT + 3) / 4;         // k-chunks (of 4 octets) per (dz, dy) row of the window
+    constexpr int CPR = (K * OPT + 3) / 4;         // k-chunks (of 4 octets) per (dz, dy) row of the window
+    constexpr int PAD = K / 2, SZ = KD == 1 ? 1 : STRIDE, PZ = KD / 2;
     constexpr int NT = (COUT + 15) / 16, NP = PASSES == 3 ? 2 : 1;
-    constexpr int IY = STRIDE * (RT - 1) + 3;      // input rows under RT output rows
-    constexpr bool WREG = 3 * CPR * NT * NP * 4 <= 128 && RT > 1;       // weights of a z-tap in registers
+    constexpr int IY = STRIDE * (RT - 1) + K;      // input rows under RT output rows
+    constexpr bool WREG = K == 3 && K * CPR * NT * NP * 4 <= 128 && RT > 1;       // weights of a z-tap in registers
     static_assert(CIN % 8 == 0 && (!PRE || OPT == 1 || OPT == 2 || OPT == 4 || OPT == 8), "channel counts");
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvArgs a) {
     // (voxel n, octet 4 c + g) is then one 16-byte LDS read per part.  (Read per window from global memory every octet
     // was fetched, normalised and rounded three times - and the loads were 32-byte pieces at a stride of C floats.)
     // No barrier: the strip belongs to one wave, and a wave's LDS instructions execute in order.
-    constexpr int SP = STRIDE * 15 + 3, NO = SP * OPT, NR = (NO + 63) / 64;
+    constexpr int SP = STRIDE * 15 + K, NO = SP * OPT, NR = (NO + 63) / 64;
     constexpr int PSTR = OPT + 1;                   // octets per pixel in LDS: one of padding (spreads the banks)
     constexpr int PART_BYTES = SP * PSTR * 16;
     __shared__ __attribute__((aligned(16))) char strips[4][NP * PART_BYTES];
@@ -126,10 +129,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvArgs a) {
     float4 pf[NR][2], pf2[DEEP ? NR : 1][2];
     unsigned pf_ok = 0, pf2_ok = 0;
     auto fetch_row = [&](int k, int z, int y0, int x0, auto &dst, unsigned &dst_ok) {   // row k of the tile's 3 IY
-        const int zi = STRIDE * z + k / IY - 1, yi = STRIDE * y0 - 1 + k % IY;
-        const bool row_ok = k < 3 * IY && (unsigned)zi < (unsigned)a.Di && (unsigned)yi < (unsigned)a.Hi;
+        const int zi = SZ * z + k / IY - PZ, yi = STRIDE * y0 - PAD + k % IY;
+        const bool row_ok = k < KD * IY && (unsigned)zi < (unsigned)a.Di && (unsigned)yi < (unsigned)a.Hi;
         const float *base = a.in + (((size_t)(row_ok ? zi : 0) * a.Hi + (row_ok ? yi : 0)) * a.Wi) * CIN;
-        const int xs = STRIDE * x0 - 1;
+        const int xs = STRIDE * x0 - PAD;
         dst_ok = 0;
 #pragma unroll
         for (int r = 0; r < NR; r++) {
@@ -167,16 +170,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvArgs a) {
             for (int nt = 0; nt < NT; nt++) acc[ry][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         fetch_row(0, z, y0, x0, pf, pf_ok);
         if constexpr (DEEP) fetch_row(1, z, y0, x0, pf2, pf2_ok);
-        for (int dz = 0; dz < 3; dz++) {
-            const int zi = STRIDE * z + dz - 1;
+        for (int dz = 0; dz < KD; dz++) {
+            const int zi = SZ * z + dz - PZ;
             const bool z_ok = (unsigned)zi < (unsigned)a.Di;
             // the weights of this z-tap stay in registers over the tile's input rows when they fit (the three (dy)
             // operands of a chunk are used again by every input row: read per use they were 2/3 of the kernel's L1 traffic)
-            bf16x8 wreg[WREG ? 3 : 1][WREG ? CPR : 1][WREG ? NT : 1][NP];
+            bf16x8 wreg[WREG ? K : 1][WREG ? CPR : 1][WREG ? NT : 1][NP];
             if constexpr (WREG) {
                 if (z_ok) {
 #pragma unroll
-                    for (int dy = 0; dy < 3; dy++)
+                    for (int dy = 0; dy < K; dy++)
 #pragma unroll
                         for (int c = 0; c < CPR; c++)
 #pragma unroll
@@ -184,12 +187,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvArgs a) {
 #pragma unroll
                                 for (int pt = 0; pt < NP; pt++)
                                     wreg[dy][c][nt][pt] = __builtin_bit_cast(
-                                        bf16x8, a.w[((size_t)(((dz * 3 + dy) * CPR + c) * NT + nt) * NP + pt) * 64 + lane]);
+                                        bf16x8, a.w[((size_t)(((dz * K + dy) * CPR + c) * NT + nt) * NP + pt) * 64 + lane]);
                 }
             }
 #pragma unroll
             for (int iy = 0; iy < IY; iy++) {
-                const int yi = STRIDE * y0 - 1 + iy;
+                const int yi = STRIDE * y0 - PAD + iy;
                 const bool row_ok = z_ok && (unsigned)yi < (unsigned)a.Hi;
                 if (row_ok) stage();
                 __builtin_amdgcn_wave_barrier();
@@ -206,12 +209,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int c = 0; c < CPR; c++) {
                     const int o = 4 * c + g, p = o / OPT, q = o - p * OPT;
-                    const bool okc = o < 3 * OPT;
+                    const bool okc = o < K * OPT;
                     const char *src = strip + ((okc ? STRIDE * n + p : 0) * PSTR + (okc ? q : 0)) * 16;
 #pragma unroll
                     for (int pt = 0; pt < NP; pt++) {
                         bf16x8 v = *reinterpret_cast<const bf16x8 *>(src + pt * PART_BYTES);
-                        if (4 * c + 3 >= 3 * OPT) {                   // a chunk with padding octets (zero weights: keep stale LDS bits out)
+                        if (4 * c + 3 >= K * OPT) {                   // a chunk with padding octets (zero weights: keep stale LDS bits out)
                             const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
                             v = okc ? v : z8;
                         }
@@ -222,8 +225,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int ry = 0; ry < RT; ry++) {
                     const int dy = iy - STRIDE * ry;                  // compile-time after unrolling
-                    if (dy < 0 || dy > 2) continue;
-                    const uint4 *wrow = a.w + (size_t)((dz * 3 + dy) * CPR) * NT * NP * 64 + lane;
+                    if (dy < 0 || dy >= K) continue;
+                    const uint4 *wrow = a.w + (size_t)((dz * K + dy) * CPR) * NT * NP * 64 + lane;
 #pragma unroll
                     for (int c = 0; c < CPR; c++)
 #pragma unroll
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(256) void costreg_out_kernel(const float4 *__restri
         out[(size_t)c * nvox + i] = leaky(fmaf(va[c], pa[c], pa[8 + c])) + leaky(fmaf(vb[c], pb[c], pb[8 + c]));
 }
 
-template <int CIN, int COUT, int STRIDE, bool PRE>
+template <int CIN, int COUT, int STRIDE, bool PRE, int K = 3, int KD = 3>
 int launch_conv(const ConvArgs &a0, int passes, hipStream_t st) {
     ConvArgs a = a0;
     const long long rows = (long long)a.Do * a.Ho * ((a.Wo + 15) / 16);
@@ -484,7 +487,7 @@ int launch_conv(const ConvArgs &a0, int passes, hipStream_t st) {
     const int RT = small ? 1 : 4;
     a.n_xb = (a.Wo + 15) / 16, a.n_yg = (a.Ho + RT - 1) / RT, a.n_tiles = a.Do * a.n_yg * a.n_xb;
     const int grid = a.n_tiles < 4096 ? (a.n_tiles + 3) / 4 : 1024;
-#define ZEST_CONV(P, R) hipLaunchKernelGGL((conv3d_mfma_kernel<CIN, COUT, STRIDE, P, PRE, R>), dim3(grid), dim3(256), 0, st, a)
+#define ZEST_CONV(P, R) hipLaunchKernelGGL((conv3d_mfma_kernel<CIN, COUT, STRIDE, P, PRE, R, K, KD>), dim3(grid), dim3(256), 0, st, a)
     if (passes == 1) { if (small) ZEST_CONV(1, 1); else ZEST_CONV(1, 4); }
     else { if (small) ZEST_CONV(3, 1); else ZEST_CONV(3, 4); }
 #undef ZEST_CONV
@@ -495,17 +498,25 @@ int launch_conv(const ConvArgs &a0, int passes, hipStream_t st) {
 
 extern "C" int zest_costreg_stat_rows(void) { return kStatRows + 1; }
 
-extern "C" size_t zest_costreg_packed_bytes(int cin_pad, int cout, int passes) {
-    const int opt = cin_pad / 8, cpr = (3 * opt + 3) / 4, nt = (cout + 15) / 16;
-    return (size_t)9 * cpr * nt * (passes == 3 ? 2 : 1) * 1024;
+static size_t conv_packed_bytes(int cin, int cout, int passes, int k, int kd) {
+    const int opt = cin / 8, cpr = (k * opt + 3) / 4, nt = (cout + 15) / 16;
+    return (size_t)kd * k * cpr * nt * (passes == 3 ? 2 : 1) * 1024;
+}
+extern "C" size_t zest_costreg_packed_bytes(int cin, int cout, int passes) { return conv_packed_bytes(cin, cout, passes, 3, 3); }
+extern "C" size_t zest_conv2d_packed_bytes(int cin, int cout, int k, int passes) { return conv_packed_bytes(cin, cout, passes, k, 1); }
+
+static int conv_check(const char *who, const float *in, const void *w_packed, float *out, double *stats, int stride, int passes,
+                      int Di, int Hi, int Wi, int cin) {
+    ZEST_CHECK_ARG(in && w_packed && out && stats, "%s: null pointer", who);
+    ZEST_CHECK_ARG(((uintptr_t)in | (uintptr_t)out | (uintptr_t)w_packed) % 16 == 0, "%s: pointers must be 16-byte aligned", who);
+    ZEST_CHECK_ARG((stride == 1 || stride == 2) && (passes == 1 || passes == 3), "%s: stride %d, passes %d", who, stride, passes);
+    ZEST_CHECK_ARG(Di >= 1 && Hi >= 1 && Wi >= 1 && (long long)Di * Hi * Wi * cin < (1ll << 31), "%s: bad shape", who);
+    return 0;
 }
 
 extern "C" int zest_costreg_conv_fwd(const float *in, const float *pre, const void *w_packed, int cin, int cout, int stride,
                                      int passes, int Di, int Hi, int Wi, float *out, double *stats, void *stream) {
-    ZEST_CHECK_ARG(in && w_packed && out && stats, "zest_costreg_conv_fwd: null pointer");
-    ZEST_CHECK_ARG(((uintptr_t)in | (uintptr_t)out | (uintptr_t)w_packed) % 16 == 0, "zest_costreg_conv_fwd: pointers must be 16-byte aligned");
-    ZEST_CHECK_ARG((stride == 1 || stride == 2) && (passes == 1 || passes == 3), "zest_costreg_conv_fwd: stride %d, passes %d", stride, passes);
-    ZEST_CHECK_ARG(Di >= 1 && Hi >= 1 && Wi >= 1 && (long long)Di * Hi * Wi * cin < (1ll << 31), "zest_costreg_conv_fwd: bad shape");
+    if (int e = conv_check("zest_costreg_conv_fwd", in, w_packed, out, stats, stride, passes, Di, Hi, Wi, cin)) return e;
     ConvArgs a{};
     a.in = in, a.pre = pre, a.w = (const uint4 *)w_packed, a.out = out, a.stats = stats;
     a.Di = Di, a.Hi = Hi, a.Wi = Wi;
@@ -526,6 +537,32 @@ extern "C" int zest_costreg_conv_fwd(const float *in, const float *pre, const vo
         return (int)hipErrorInvalidValue;
     }
     ZEST_RETURN_LAUNCH("zest_costreg_conv_fwd");
+}
+
+// 2-D convolution of a batch of N images [N,Hi,Wi,cin] (channels-last) with the same machinery: Conv2d(cin -> cout, k,
+// stride, padding k / 2, no bias) on act(norm(in)) (pre NULL: on `in` itself): the layers of FeatureNet
+extern "C" int zest_conv2d_fwd(const float *in, const float *pre, const void *w_packed, int cin, int cout, int k, int stride,
+                               int passes, int N, int Hi, int Wi, float *out, double *stats, void *stream) {
+    if (int e = conv_check("zest_conv2d_fwd", in, w_packed, out, stats, stride, passes, N, Hi, Wi, cin)) return e;
+    ConvArgs a{};
+    a.in = in, a.pre = pre, a.w = (const uint4 *)w_packed, a.out = out, a.stats = stats;
+    a.Di = N, a.Hi = Hi, a.Wi = Wi;
+    a.Do = N, a.Ho = (Hi - 1) / stride + 1, a.Wo = (Wi - 1) / stride + 1;
+    const hipStream_t st = (hipStream_t)stream;
+    const int key = ((cin * 100 + cout) * 10 + k) * 10 + stride;
+    ZEST_CHECK_ARG(pre || key == 80831, "zest_conv2d_fwd: only the first layer (8 -> 8, k 3) reads an un-normalised input");
+    if (!pre) launch_conv<8, 8, 1, false, 3, 1>(a, passes, st);           // conv0.0 (3 channels, padded)
+    else switch (key) {     // the layers of FeatureNet (reference networks.py:967-979)
+    case 80831: launch_conv<8, 8, 1, true, 3, 1>(a, passes, st); break;       // conv0.1
+    case 81652: launch_conv<8, 16, 2, true, 5, 1>(a, passes, st); break;      // conv1.0
+    case 161631: launch_conv<16, 16, 1, true, 3, 1>(a, passes, st); break;    // conv1.1, conv1.2
+    case 163252: launch_conv<16, 32, 2, true, 5, 1>(a, passes, st); break;    // conv2.0
+    case 323231: launch_conv<32, 32, 1, true, 3, 1>(a, passes, st); break;    // conv2.1, conv2.2
+    default:
+        zest_set_error("zest_conv2d_fwd: no kernel for %d -> %d channels, k %d, stride %d", cin, cout, k, stride);
+        return (int)hipErrorInvalidValue;
+    }
+    ZEST_RETURN_LAUNCH("zest_conv2d_fwd");
 }
 
 extern "C" size_t zest_costreg_deconv_packed_bytes(int cin, int cout, int passes) {

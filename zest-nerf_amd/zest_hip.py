@@ -84,6 +84,8 @@ _SIGS = {
     "zest_homo_warp_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "zest_volume_cost_cl_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "zest_costreg_stat_rows": (_i, []),
+    "zest_conv2d_packed_bytes": (_sz, [_i, _i, _i, _i]),
+    "zest_conv2d_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "zest_costreg_packed_bytes": (_sz, [_i, _i, _i]),
     "zest_costreg_conv_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "zest_costreg_deconv_packed_bytes": (_sz, [_i, _i, _i]),
@@ -336,17 +338,23 @@ def volume_cost(feats, imgs_lr, proj, depth, pad=0, return_feats_cl=False):
 COST_CL_CHANNELS = 48            # channels of the channels-last cost volume (41 used for V = 3)
 
 
-def volume_cost_cl(feats, imgs_lr, proj, depth, pad=0):
+def volume_cost_cl(feats, imgs_lr, proj, depth, pad=0, feats_cl=None):
     """The plane-sweep cost volume for the HIP regularisation net: [D, H+2pad, W+2pad, 48] channels-last
-    (channels 3V+32 .. 47 are zero), no masks.  Arguments as volume_cost."""
-    feats, imgs_lr = _dev(feats, "feats"), _dev(imgs_lr, "imgs")
+    (channels 3V+32 .. 47 are zero), no masks.  Arguments as volume_cost; feats_cl [V,H,W,32]: the features already
+    channels-last (FeatureNet.forward_hip) instead of `feats`."""
+    imgs_lr = _dev(imgs_lr, "imgs")
     proj, depth = _dev(proj, "proj_mats"), _dev(depth, "depth_values")
+    if feats_cl is not None:
+        feats_cl = _dev(feats_cl, "feats_cl")
+        feats = feats_cl.permute(0, 3, 1, 2)                 # shape bookkeeping only
+    else:
+        feats = _dev(feats, "feats")
     V, Cc, H, W = feats.shape
     if tuple(imgs_lr.shape) != (V, 3, H, W) or tuple(proj.shape) != (V - 1, 3, 4) or depth.dim() != 1:
         raise RuntimeError("zest_hip.volume_cost_cl: feats %s imgs %s proj %s depth %s"
                            % (tuple(feats.shape), tuple(imgs_lr.shape), tuple(proj.shape), tuple(depth.shape)))
     D, Hp, Wp = depth.shape[0], H + 2 * pad, W + 2 * pad
-    fcl, icl = nchw_to_nhwc(feats), images_to_cl(imgs_lr)
+    fcl, icl = (feats_cl if feats_cl is not None else nchw_to_nhwc(feats)), images_to_cl(imgs_lr)
     out = torch.empty(D, Hp, Wp, COST_CL_CHANNELS, device=feats.device, dtype=torch.float32)
     _check(lib().zest_volume_cost_cl_fwd(_ptr(fcl), _ptr(icl), _ptr(proj), _ptr(depth), V, Cc, D, H, W, pad,
                                          _ptr(out), _stream(feats)), "zest_volume_cost_cl_fwd")
@@ -383,6 +391,25 @@ def costreg_conv(x, pre, w_packed, cout, stride, passes, stats):
     out = torch.empty(o(D), o(H), o(W), cout, device=x.device, dtype=torch.float32)
     _check(lib().zest_costreg_conv_fwd(_ptr(x), _ptr(pre), _ptr(w_packed), cin, cout, stride, passes, D, H, W,
                                        _ptr(out), _ptr(stats), _stream(x)), "zest_costreg_conv_fwd")
+    return out
+
+
+def conv2d_cl(x, pre, w_packed, cout, k, stride, passes, stats):
+    """x [N,H,W,cin] raw channels-last; pre [2,cin] or None; -> raw [N,Ho,Wo,cout] (Conv2d k x k, padding k//2, no bias,
+    on act(norm(x))); stats: costreg_stats(cout)."""
+    x = _dev(x, "x")
+    N, H, W, cin = x.shape
+    need = int(lib().zest_conv2d_packed_bytes(cin, cout, k, passes))
+    if w_packed.numel() * w_packed.element_size() != need or not w_packed.is_cuda:
+        raise RuntimeError("zest_hip.conv2d_cl: packed weights of %d bytes, %d -> %d channels, k %d, %d passes take %d"
+                           % (w_packed.numel() * w_packed.element_size(), cin, cout, k, passes, need))
+    if pre is not None and (tuple(pre.shape) != (2, cin) or pre.dtype != torch.float32 or not pre.is_contiguous()):
+        raise RuntimeError("zest_hip.conv2d_cl: pre %s for %d channels" % (tuple(pre.shape), cin))
+    _check_stats(stats, cout, "conv2d_cl")
+    o = lambda n: (n - 1) // stride + 1
+    out = torch.empty(N, o(H), o(W), cout, device=x.device, dtype=torch.float32)
+    _check(lib().zest_conv2d_fwd(_ptr(x), _ptr(pre), _ptr(w_packed), cin, cout, k, stride, passes, N, H, W,
+                                 _ptr(out), _ptr(stats), _stream(x)), "zest_conv2d_fwd")
     return out
 
 

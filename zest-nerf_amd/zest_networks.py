@@ -356,6 +356,43 @@ class ActivatedBatchNorm(nn.BatchNorm2d):
         return torch.nn.functional.leaky_relu(y, self.activation_param) if self.activation == "leaky_relu" else y
 
 
+def pack_conv_weights(w, passes):
+    """Conv3d weight [cout,cin,KD,K,K] (or Conv2d [cout,cin,K,K]: KD = 1) -> MFMA A operands of csrc/costreg.hip,
+    [dz][dy][chunk][16-row tile][hi, lo][lane] x 8 bf16: lane (m = l & 15, g = l >> 4) of chunk c holds output channel
+    16 nt + m against octet o = 4 c + g of the x-window (pixel o // (cin/8), channels 8 (o % (cin/8)) ..+7), zero beyond
+    the window / the channels (cin is padded to a multiple of 8)."""
+    if w.dim() == 4:
+        w = w.unsqueeze(2)
+    cout, cin, KD, K, _ = w.shape
+    opt = (cin + 7) // 8
+    cpr, nt, dev = (K * opt + 3) // 4, (cout + 15) // 16, w.device
+    lane, e = torch.arange(64, device=dev), torch.arange(8, device=dev)
+    o = 4 * torch.arange(cpr, device=dev).view(cpr, 1, 1, 1) + (lane >> 4).view(1, 1, 64, 1)
+    px, ci = o // opt, 8 * (o % opt) + e.view(1, 1, 1, 8)
+    co = 16 * torch.arange(nt, device=dev).view(1, nt, 1, 1) + (lane & 15).view(1, 1, 64, 1)
+    valid = ((o < K * opt) & (ci < cin) & (co < cout)).expand(cpr, nt, 64, 8)
+    full = (cpr, nt, 64, 8)
+    vals = w.detach().float()[co.clamp(max=cout - 1).expand(full), ci.clamp(max=cin - 1).expand(full), :, :,
+                              px.clamp(max=K - 1).expand(full)]                     # [cpr,nt,64,8,dz,dy]
+    vals = (vals * valid[..., None, None]).permute(4, 5, 0, 1, 2, 3)
+    hi = vals.to(torch.bfloat16)
+    parts = [hi] if passes == 1 else [hi, (vals - hi.float()).to(torch.bfloat16)]
+    return torch.stack(parts, 4).contiguous().view(torch.int16).view(-1)           # [KD,K,cpr,nt,parts,64,8]
+
+
+def _cached_packs(module, passes, weights, build):
+    """Packed weights of `module`, rebuilt when a weight tensor is replaced or modified in place."""
+    key = (passes,) + tuple((id(w), w._version, str(w.device)) for w in weights)
+    cache = module.__dict__.get("_zest_packs")
+    if cache is None or cache[0] != key:
+        module.__dict__["_zest_packs"] = cache = (key, build())
+    return cache[1]
+
+
+def _hip_norm(bn):
+    return isinstance(bn, ActivatedBatchNorm) and bn.activation == "leaky_relu" and abs(bn.activation_param - 0.01) < 1e-12
+
+
 class ConvBnReLU(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, pad=1,
                  norm_act=ActivatedBatchNorm):
@@ -393,6 +430,42 @@ class FeatureNet(nn.Module):
                                    ConvBnReLU(32, 32, 3, 1, 1, norm_act=norm_act),
                                    ConvBnReLU(32, 32, 3, 1, 1, norm_act=norm_act))
         self.toplayer = nn.Conv2d(32, 32, 1)
+
+    # ---- HIP path, no autograd: the eight Conv + norm + activation layers as 2-D calls of the regularisation net's
+    # convolution kernel (csrc/costreg.hip, one-slice-deep windows), the 1x1 top layer as one matrix product
+    _HIP_LAYERS = (("conv0", 0), ("conv0", 1), ("conv1", 0), ("conv1", 1), ("conv1", 2), ("conv2", 0), ("conv2", 1), ("conv2", 2))
+    _HIP_SHAPES = ((3, 8, 3, 1), (8, 8, 3, 1), (8, 16, 5, 2), (16, 16, 3, 1), (16, 16, 3, 1), (16, 32, 5, 2), (32, 32, 3, 1),
+                   (32, 32, 3, 1))
+
+    def hip_supported(self):
+        convs = [getattr(self, s)[i] for s, i in self._HIP_LAYERS]
+        shapes = tuple((m.conv.in_channels, m.conv.out_channels, m.conv.kernel_size[0], m.conv.stride[0]) for m in convs)
+        top = self.toplayer
+        return (shapes == self._HIP_SHAPES and all(_hip_norm(m.bn) for m in convs) and top.kernel_size == (1, 1)
+                and top.in_channels == top.out_channels == 32)
+
+    def forward_hip(self, imgs, passes=3):
+        """imgs [N,3,H,W] -> top-level features, channels-last [N,H/4,W/4,32] (what the plane sweep reads), no graph."""
+        convs = [getattr(self, s)[i] for s, i in self._HIP_LAYERS]
+        packs = _cached_packs(self, passes, [m.conv.weight for m in convs],
+                              lambda: [pack_conv_weights(m.conv.weight, passes) for m in convs])
+        chans = [m.bn.num_features for m in convs]
+        offs = [0]
+        for c in chans:
+            offs.append(offs[-1] + 2 * c)
+        rows, dev = zest_hip.costreg_stat_rows(), imgs.device
+        stats_all = torch.empty(rows * offs[-1], device=dev, dtype=torch.float64)
+        pre_all = torch.empty(offs[-1], device=dev, dtype=torch.float32)
+        x = torch.nn.functional.pad(imgs.float().permute(0, 2, 3, 1), (0, 5)).contiguous()        # [N,H,W,8]
+        pre = None
+        for i, m in enumerate(convs):
+            st = stats_all[rows * offs[i]:rows * offs[i + 1]].view(rows, 2, chans[i])
+            x = zest_hip.conv2d_cl(x, pre, packs[i], chans[i], m.conv.kernel_size[0], m.conv.stride[0], passes, st)
+            pre = zest_hip.costreg_bn(st, x.numel() // chans[i], m.bn, m.bn.training, pre_all[offs[i]:offs[i + 1]].view(2, chans[i]))
+        act = torch.nn.functional.leaky_relu(x * pre[0] + pre[1], 0.01)
+        top = self.toplayer
+        bias = top.bias if top.bias is not None else act.new_zeros(32)
+        return torch.addmm(bias.to(act.dtype), act.view(-1, 32), top.weight.view(32, 32).t().to(act.dtype)).float().view(x.shape)
 
     def _upsample_add(self, x, y):
         return torch.nn.functional.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True) + y
@@ -432,29 +505,11 @@ class CostRegNet(nn.Module):
         """The HIP kernels cover the reference's layer shapes with leaky-ReLU(0.01) norms."""
         bns = [getattr(self, n).bn for n, _ in self._HIP_CONVS] + [getattr(self, n)[1] for n in self._HIP_UPS]
         return (self.conv0.conv.in_channels <= zest_hip.COST_CL_CHANNELS and self.conv0.conv.out_channels == 8
-                and all(isinstance(b, ActivatedBatchNorm) and b.activation == "leaky_relu"
-                        and abs(b.activation_param - 0.01) < 1e-12 for b in bns))
+                and all(_hip_norm(b) for b in bns))
 
     @staticmethod
     def _pack_conv(w, passes):
-        """Conv3d weight [cout,cin,3,3,3] -> MFMA A operands [dz][dy][chunk][16-row tile][hi, lo][lane] x 8 bf16:
-        lane (m = l & 15, g = l >> 4) of chunk c holds output channel 16 nt + m against octet o = 4 c + g of the
-        x-window (pixel o // (cin/8), channels 8 (o % (cin/8)) ..+7), zero beyond the window / the channels."""
-        cout, cin = w.shape[:2]
-        opt = (cin + 7) // 8
-        cpr, nt, dev = (3 * opt + 3) // 4, (cout + 15) // 16, w.device
-        lane, e = torch.arange(64, device=dev), torch.arange(8, device=dev)
-        o = 4 * torch.arange(cpr, device=dev).view(cpr, 1, 1, 1) + (lane >> 4).view(1, 1, 64, 1)
-        px, ci = o // opt, 8 * (o % opt) + e.view(1, 1, 1, 8)
-        co = 16 * torch.arange(nt, device=dev).view(1, nt, 1, 1) + (lane & 15).view(1, 1, 64, 1)
-        valid = ((o < 3 * opt) & (ci < cin) & (co < cout)).expand(cpr, nt, 64, 8)
-        full = (cpr, nt, 64, 8)
-        vals = w.detach().float()[co.clamp(max=cout - 1).expand(full), ci.clamp(max=cin - 1).expand(full), :, :,
-                                  px.clamp(max=2).expand(full)]                     # [cpr,nt,64,8,dz,dy]
-        vals = (vals * valid[..., None, None]).permute(4, 5, 0, 1, 2, 3)
-        hi = vals.to(torch.bfloat16)
-        parts = [hi] if passes == 1 else [hi, (vals - hi.float()).to(torch.bfloat16)]
-        return torch.stack(parts, 4).contiguous().view(torch.int16).view(-1)       # [3,3,cpr,nt,parts,64,8]
+        return pack_conv_weights(w, passes)
 
     @staticmethod
     def _pack_deconv(w, passes):
@@ -487,14 +542,13 @@ class CostRegNet(nn.Module):
 
     def _hip_packs(self, passes):
         ws = [getattr(self, n).conv.weight for n, _ in self._HIP_CONVS] + [getattr(self, n)[0].weight for n in self._HIP_UPS]
-        key = (passes,) + tuple((id(w), w._version, str(w.device)) for w in ws)
-        cache = self.__dict__.get("_zest_packs")
-        if cache is None or cache[0] != key:
-            packs = {n: self._pack_conv(getattr(self, n).conv.weight, passes) for n, _ in self._HIP_CONVS}
+
+        def build():
+            packs = {n: pack_conv_weights(getattr(self, n).conv.weight, passes) for n, _ in self._HIP_CONVS}
             for n in self._HIP_UPS:
                 packs[n] = self._pack_deconv(getattr(self, n)[0].weight, passes)
-            self.__dict__["_zest_packs"] = cache = (key, packs)
-        return cache[1]
+            return packs
+        return _cached_packs(self, passes, ws, build)
 
     def forward_hip(self, cost_cl, passes=3):
         """cost_cl [D,H,W,48] channels-last (zest_hip.volume_cost_cl) -> encoding volume [1,8,D,H,W], no graph.
@@ -584,9 +638,22 @@ class MVSNet(nn.Module):
         if vis_test:
             raise NotImplementedError("MVSNet.forward: vis_test dumps are a debugging aid of the reference")
         B, V, _, H, W = imgs.shape
-        feats, _ = self.feature(imgs.reshape(B * V, 3, H, W))
-        feats = feats.view(B, V, *feats.shape[1:])
         D = 128
+        half = lambda n: (n - 1) // 2 + 1
+        Hf, Wf = half(half(H)), half(half(W))
+        # whole-image evaluation (no graph): feature pyramid, plane sweep and regularisation net as HIP kernels
+        # (csrc/costreg.hip); bf16 operands under autocast (--precision 16), split-bf16 pairs otherwise
+        hip = (not torch.is_grad_enabled() and imgs.is_cuda and B == 1 and 3 * V + 32 <= zest_hip.COST_CL_CHANNELS
+               and not return_color and not (D % 8 or (Hf + 2 * pad) % 8 or (Wf + 2 * pad) % 8)
+               and getattr(self, "zest_hip_costreg", True) and self.cost_reg_2.hip_supported())
+        passes = 1 if torch.is_autocast_enabled() else 3
+        feats_cl = None
+        if hip and self.feature.hip_supported():
+            feats_cl = self.feature.forward_hip(imgs[0], passes)
+            feats = feats_cl.permute(0, 3, 1, 2)[None]
+        else:
+            feats, _ = self.feature(imgs.reshape(B * V, 3, H, W))
+            feats = feats.view(B, V, *feats.shape[1:])
         t_vals = torch.linspace(0., 1., steps=D, device=imgs.device, dtype=imgs.dtype)
         near, far = near_far
         if not lindisp:
@@ -594,18 +661,12 @@ class MVSNet(nn.Module):
         else:
             depth_values = 1. / (1. / near * (1. - t_vals) + 1. / far * t_vals)
         depth_values = depth_values.unsqueeze(0)
-        Dp, Hp, Wp = D, feats.shape[-2] + 2 * pad, feats.shape[-1] + 2 * pad
-        if (not torch.is_grad_enabled() and imgs.is_cuda and B == 1 and 3 * V + 32 <= zest_hip.COST_CL_CHANNELS
-                and not return_color and not (Dp % 8 or Hp % 8 or Wp % 8) and getattr(self, "zest_hip_costreg", True)
-                and self.cost_reg_2.hip_supported()):
-            # whole-image evaluation: plane sweep straight into the channels-last layout of the HIP regularisation
-            # net (csrc/costreg.hip); bf16 operands under autocast (--precision 16), split-bf16 pairs otherwise
-            Hf, Wf = feats.shape[-2:]
+        if hip:
             imgs_lr = torch.nn.functional.interpolate(imgs.reshape(B * V, *imgs.shape[2:]), (Hf, Wf), mode="bilinear",
                                                       align_corners=False)
-            cost_cl = zest_hip.volume_cost_cl(feats[0].float(), imgs_lr.float(), proj_mats[0, 1:], depth_values[0], pad)
-            volume_feat = self.cost_reg_2.forward_hip(cost_cl, passes=1 if torch.is_autocast_enabled() else 3)
-            return volume_feat, feats, depth_values
+            cost_cl = zest_hip.volume_cost_cl(None if feats_cl is not None else feats[0].float(), imgs_lr.float(),
+                                              proj_mats[0, 1:], depth_values[0], pad, feats_cl=feats_cl)
+            return self.cost_reg_2.forward_hip(cost_cl, passes=passes), feats, depth_values
         cost_vol, in_masks = self.build_volume_cost(imgs, feats, proj_mats, depth_values, pad=pad)
         if return_color:
             feats = torch.cat((cost_vol[:, :V * 3].view(B, V, 3, *cost_vol.shape[2:]), in_masks.unsqueeze(2)), dim=2)

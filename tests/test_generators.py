@@ -198,3 +198,28 @@ def test_forward_val_builds_the_two_volumes_on_two_streams(hip):
             assert all(torch.equal(a, b) for a, b in zip(outs[-1], again))
     for other in outs[1:]:
         assert all(torch.equal(a, b) for a, b in zip(outs[0], other))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", [32, 16])
+def test_builder_graph_replay_equals_direct_calls(hip, precision):
+    """The all-HIP volume builder is recorded as a HIP graph at its first whole-image call and replayed afterwards
+    (args.zest_graph_builders, default on): the volumes are those of direct calls bit for bit, for new inputs too, the
+    norms' step counters advance once per call, and a weight update makes the next call record again."""
+    x, x2 = _batch(91), _batch(92)
+    gen, ref = (_generator(_args(chunk=256, precision=precision, zest_graph_builders=g)) for g in (True, False))
+    ref.load_state_dict(gen.state_dict())
+    with torch.no_grad():
+        for k, batch in enumerate((x, x, x2, x)):
+            a, b = gen._scene(batch, bn_batch_stats=True), ref._scene(batch, bn_batch_stats=True)
+            assert torch.equal(a["vol_s"], b["vol_s"]) and torch.equal(a["vol_d"], b["vol_d"]), k
+        assert "_zest_builder_graphs" in gen.__dict__ and "_zest_builder_graphs" not in ref.__dict__
+        bn_a, bn_b = gen.encoding_net.cost_reg_2.conv3.bn, ref.encoding_net.cost_reg_2.conv3.bn
+        assert int(bn_a.num_batches_tracked) == int(bn_b.num_batches_tracked) == 4
+        assert torch.equal(bn_a.running_var, bn_b.running_var)
+        for g in (gen, ref):
+            g.encoding_net.cost_reg_2.conv2.conv.weight.mul_(1.25)
+        graph = gen._zest_builder_graphs[id(gen.encoding_net)]["graph"]
+        a, b = gen._scene(x2, bn_batch_stats=True), ref._scene(x2, bn_batch_stats=True)
+        assert torch.equal(a["vol_s"], b["vol_s"])
+        assert gen._zest_builder_graphs[id(gen.encoding_net)]["graph"] is not graph

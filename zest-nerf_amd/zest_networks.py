@@ -631,6 +631,16 @@ class MVSNet(nn.Module):
             img_feat, masks = zest_hip.volume_cost(feats[0], imgs_lr, proj_mats[0, 1:], depth, pad)
         return img_feat[None], masks[None]
 
+    def hip_path(self, imgs, pad=0):
+        """True when forward(imgs, ..., pad) runs on the HIP kernels alone: no autograd, the reference's layer shapes,
+        a volume of whole octets per axis."""
+        B, V, _, H, W = imgs.shape
+        half = lambda n: (n - 1) // 2 + 1
+        Hf, Wf = half(half(H)), half(half(W))
+        return (not torch.is_grad_enabled() and imgs.is_cuda and B == 1 and 3 * V + 32 <= zest_hip.COST_CL_CHANNELS
+                and not ((Hf + 2 * pad) % 8 or (Wf + 2 * pad) % 8) and getattr(self, "zest_hip_costreg", True)
+                and self.cost_reg_2.hip_supported())
+
     def forward(self, imgs, proj_mats, near_far, pad=0, return_color=False, lindisp=False,
                 vis_test=False, test_dir=None):
         """-> (volume_feat [1,8,128,H/4+2pad,W/4+2pad], feats, depth_values) (reference networks.py:1142-1238).
@@ -641,11 +651,9 @@ class MVSNet(nn.Module):
         D = 128
         half = lambda n: (n - 1) // 2 + 1
         Hf, Wf = half(half(H)), half(half(W))
-        # whole-image evaluation (no graph): feature pyramid, plane sweep and regularisation net as HIP kernels
+        # whole-image evaluation (no autograd): feature pyramid, plane sweep and regularisation net as HIP kernels
         # (csrc/costreg.hip); bf16 operands under autocast (--precision 16), split-bf16 pairs otherwise
-        hip = (not torch.is_grad_enabled() and imgs.is_cuda and B == 1 and 3 * V + 32 <= zest_hip.COST_CL_CHANNELS
-               and not return_color and not (D % 8 or (Hf + 2 * pad) % 8 or (Wf + 2 * pad) % 8)
-               and getattr(self, "zest_hip_costreg", True) and self.cost_reg_2.hip_supported())
+        hip = not return_color and self.hip_path(imgs, pad)
         passes = 1 if torch.is_autocast_enabled() else 3
         feats_cl = None
         if hip and self.feature.hip_supported():
@@ -705,7 +713,35 @@ class _Generator(nn.Module):
         amp = int(getattr(self.args, "precision", 32) or 32) == 16 and imgs.is_cuda
         train = torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters())
         with torch.set_grad_enabled(train), torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            if (not train and getattr(self.args, "zest_graph_builders", True) and isinstance(net, MVSNet)
+                    and net.feature.hip_supported() and net.hip_path(imgs, self.args.pad)):
+                return self._volume_replayed(net, imgs, proj_mats, near_far)
             return net(imgs, proj_mats, near_far, pad=self.args.pad)[0].float()
+
+    def _volume_replayed(self, net, imgs, proj_mats, near_far):
+        """The all-HIP builder is ~110 kernel launches of a few microseconds each and the host is slower at issuing
+        them than the device at running them (3.4 ms of wall time for 1.8 ms of device time per image): the first
+        call with a given net, shapes and weights runs it directly and then RECORDS it as a HIP graph (recording
+        executes nothing: the norms' running estimates advance once per call, as without the graph); later calls
+        copy their inputs into the graph's buffers and replay it.  The volume is returned as a copy."""
+        key = (tuple(imgs.shape), tuple(proj_mats.shape), imgs.dtype, self.args.pad, torch.is_autocast_enabled(), net.training,
+               str(imgs.device), getattr(net, "zest_hip_costreg", True),
+               tuple((id(p), p._version) for p in net.parameters()))
+        graphs = self.__dict__.setdefault("_zest_builder_graphs", {})
+        ent = graphs.get(id(net))
+        if ent is not None and ent["key"] == key:
+            ent["imgs"].copy_(imgs), ent["proj"].copy_(proj_mats), ent["near_far"].copy_(near_far)
+            ent["graph"].replay()
+            return ent["out"].clone()
+        out = net(imgs, proj_mats, near_far, pad=self.args.pad)[0].float()
+        graphs.pop(id(net), None)
+        ent = dict(key=key, imgs=imgs.clone(), proj=proj_mats.clone(), near_far=near_far.clone().to(imgs.device), graph=torch.cuda.CUDAGraph())
+        cur = torch.cuda.current_stream(imgs.device)
+        with torch.cuda.graph(ent["graph"]):
+            ent["out"] = net(ent["imgs"], ent["proj"], ent["near_far"], pad=self.args.pad)[0].float()
+        torch.cuda.current_stream(imgs.device).wait_stream(cur)
+        graphs[id(net)] = ent
+        return out
 
 
 class MVSNeRF_G(_Generator):

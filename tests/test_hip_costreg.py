@@ -207,6 +207,10 @@ def test_regularisation_net_against_library(hip, training, passes, tol):
         net.conv2.conv.weight.mul_(1.5), ref.conv2.conv.weight.mul_(1.5)
         net.conv9[0].weight.mul_(0.5), ref.conv9[0].weight.mul_(0.5)
         assert _rel(net.forward_hip(_cl(cost), passes=passes), ref(cost[:, :41])[0]) < tol
+        # ... and when a parameter OBJECT is replaced (a fresh tensor at version 0)
+        for m in (net, ref):
+            m.conv4.conv.weight = torch.nn.Parameter(m.conv4.conv.weight.detach() * 0.5)
+        assert _rel(net.forward_hip(_cl(cost), passes=passes), ref(cost[:, :41])[0]) < tol
 
 
 @pytest.mark.parametrize("precision", [32, 16])

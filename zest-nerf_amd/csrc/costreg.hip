@@ -484,12 +484,15 @@ int launch_conv(const ConvArgs &a0, int passes, hipStream_t st) {
     const long long rows = (long long)a.Do * a.Ho * ((a.Wo + 15) / 16);
     // small levels: one row per wave so that the tiles still cover the chip
     const bool small = rows < 8192;
-    const int RT = small ? 1 : 4;
+    // rows per wave: 4 (1 on the small levels).  (8 for the first layer - fewer strips per output row, 10 / 8 instead
+    // of 6 / 4 - does not fit two waves per SIMD: 500 - 800 spilled registers.)
+    constexpr int RTL = 4;
+    const int RT = small ? 1 : RTL;
     a.n_xb = (a.Wo + 15) / 16, a.n_yg = (a.Ho + RT - 1) / RT, a.n_tiles = a.Do * a.n_yg * a.n_xb;
     const int grid = a.n_tiles < 4096 ? (a.n_tiles + 3) / 4 : 1024;
 #define ZEST_CONV(P, R) hipLaunchKernelGGL((conv3d_mfma_kernel<CIN, COUT, STRIDE, P, PRE, R, K, KD>), dim3(grid), dim3(256), 0, st, a)
-    if (passes == 1) { if (small) ZEST_CONV(1, 1); else ZEST_CONV(1, 4); }
-    else { if (small) ZEST_CONV(3, 1); else ZEST_CONV(3, 4); }
+    if (passes == 1) { if (small) ZEST_CONV(1, 1); else ZEST_CONV(1, RTL); }
+    else { if (small) ZEST_CONV(3, 1); else ZEST_CONV(3, RTL); }
 #undef ZEST_CONV
     return 0;
 }

@@ -382,10 +382,11 @@ def pack_conv_weights(w, passes):
 
 def _cached_packs(module, passes, weights, build):
     """Packed weights of `module`, rebuilt when a weight tensor is replaced or modified in place."""
-    key = (passes,) + tuple((id(w), w._version, str(w.device)) for w in weights)
+    key = (passes,) + tuple((w._version, str(w.device)) for w in weights)
     cache = module.__dict__.get("_zest_packs")
-    if cache is None or cache[0] != key:
-        module.__dict__["_zest_packs"] = cache = (key, build())
+    # the tensors themselves are compared through weak references (an id() or an address can be recycled)
+    if cache is None or cache[0] != key or len(cache[2]) != len(weights) or any(r() is not w for r, w in zip(cache[2], weights)):
+        module.__dict__["_zest_packs"] = cache = (key, build(), [weakref.ref(w) for w in weights])
     return cache[1]
 
 
@@ -724,18 +725,21 @@ class _Generator(nn.Module):
         call with a given net, shapes and weights runs it directly and then RECORDS it as a HIP graph (recording
         executes nothing: the norms' running estimates advance once per call, as without the graph); later calls
         copy their inputs into the graph's buffers and replay it.  The volume is returned as a copy."""
-        key = (tuple(imgs.shape), tuple(proj_mats.shape), imgs.dtype, self.args.pad, torch.is_autocast_enabled(), net.training,
-               str(imgs.device), getattr(net, "zest_hip_costreg", True),
-               tuple((id(p), p._version) for p in net.parameters()))
+        params = list(net.parameters())
+        norms = tuple((m.training, m.eps, m.momentum) for m in net.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm))
+        key = (tuple(imgs.shape), tuple(proj_mats.shape), imgs.dtype, self.args.pad, torch.is_autocast_enabled(), norms,
+               str(imgs.device), getattr(net, "zest_hip_costreg", True), tuple(p._version for p in params))
         graphs = self.__dict__.setdefault("_zest_builder_graphs", {})
         ent = graphs.get(id(net))
-        if ent is not None and ent["key"] == key:
+        if (ent is not None and ent["net"]() is net and ent["key"] == key and len(ent["params"]) == len(params)
+                and all(r() is p for r, p in zip(ent["params"], params))):
             ent["imgs"].copy_(imgs), ent["proj"].copy_(proj_mats), ent["near_far"].copy_(near_far)
             ent["graph"].replay()
             return ent["out"].clone()
         out = net(imgs, proj_mats, near_far, pad=self.args.pad)[0].float()
         graphs.pop(id(net), None)
-        ent = dict(key=key, imgs=imgs.clone(), proj=proj_mats.clone(), near_far=near_far.clone().to(imgs.device), graph=torch.cuda.CUDAGraph())
+        ent = dict(key=key, net=weakref.ref(net), params=[weakref.ref(p) for p in params], imgs=imgs.clone(), proj=proj_mats.clone(),
+                   near_far=near_far.clone().to(imgs.device), graph=torch.cuda.CUDAGraph())
         cur = torch.cuda.current_stream(imgs.device)
         with torch.cuda.graph(ent["graph"]):
             ent["out"] = net(ent["imgs"], ent["proj"], ent["near_far"], pad=self.args.pad)[0].float()

@@ -34,6 +34,13 @@ def sweep(tag):
     print(tag, "launches", 3 * N, "mismatching", bad)
 
 
+if len(sys.argv) > 4 and sys.argv[4] == "all":
+    # every case of the test, both modes
+    for (R, S) in [(40, 96), (40, 192), (8, 250), (9, 300), (300, 192), (1100, 160)]:
+        sc = gc.render_inputs(2100 + R + S, R=R, S=S, V=3, use_mvs=True, scene_flow=True, use_mvs_dy=True)
+        for kw in (dict(precision=16, dtype16="bf16"), dict(precision=32)):
+            sweep("%dx%d/%s" % (R, S, "bf16" if kw["precision"] == 16 else "f16x3"))
+    sys.exit(0)
 sweep("before-graph")
 import test_generators as tg
 gen = tg._generator(tg._args(chunk=256, precision=16))

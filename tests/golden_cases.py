@@ -152,6 +152,37 @@ def cost_inputs(seed, V=3, H=18, W=24, D=6, pad=2, spread=0.35):
     return dict(feats=feats, imgs=imgs, proj_mats=proj_mats, depth_values=depth_values, pad=pad)
 
 
+def builder_net_inputs(seed, D=16, H=16, W=24):
+    """Seeded state dicts (reference key names) and inputs for the two convolution stacks of the volume builder:
+    CostRegNet(32 + 9) on a [1,41,D,H,W] cost volume and FeatureNet on three [3,4H,4W]... images.  The keys and shapes come
+    from this build's modules (the generator loads the same dicts into the REFERENCE's classes with strict key
+    matching, which pins the state-dict layout too)."""
+    import zest_networks as networks
+    g = zs.rng(seed)
+
+    def fill(mod):
+        st = {}
+        for k, v in mod.state_dict().items():
+            shp = tuple(v.shape)
+            if k.endswith("num_batches_tracked"):
+                continue
+            if k.endswith("running_mean"):
+                a = g.standard_normal(shp) * 0.1
+            elif k.endswith("running_var"):
+                a = g.uniform(0.5, 2.0, size=shp)
+            elif len(shp) == 1 and k.endswith("weight"):
+                a = g.uniform(0.5, 1.5, size=shp)
+            elif len(shp) == 1:
+                a = g.standard_normal(shp) * 0.2
+            else:
+                a = g.standard_normal(shp) / np.sqrt(np.prod(shp[1:]))
+            st[k] = a.astype(np.float32)
+        return st
+    return dict(costreg_state=fill(networks.CostRegNet(41)), feature_state=fill(networks.FeatureNet()),
+                cost=g.standard_normal((1, 41, D, H, W)).astype(np.float32),
+                imgs=g.uniform(-2, 2, size=(3, 3, 4 * H, 4 * W)).astype(np.float32))
+
+
 # --------------------------------------------------------------- rendering cases
 def render_inputs(seed, R=32, S=16, V=3, use_mvs=True, scene_flow=False, use_mvs_dy=True,
                   lively=True, time_dim=0, static_shape=None):
@@ -216,6 +247,7 @@ CASES = {
     "rays_graf_patches": dict(kind="rays", seed=55, pad=2, stratified=True, torch_seed=9, patch_size=4, R=16,
                               variable_patches=True, scale_anneal=0.0025, step=3000),      # GRAF: N_rays = patch_size^2
     "homo_warp": dict(kind="homo_warp", seed=63, pad=3),
+    "builder_nets": dict(kind="builder_nets", seed=64),
     "loss_side": dict(kind="loss_side", seed=71),
     "render_static_mvs": dict(kind="render", seed=31, use_mvs=True),
     "render_static_nomvs": dict(kind="render", seed=32, use_mvs=False),
@@ -281,6 +313,8 @@ def build(case):
         return loss_inputs(c["seed"], jitter=c.get("jitter", False))
     if k == "homo_warp":
         return cost_inputs(c["seed"], V=c.get("V", 3), pad=c["pad"])
+    if k == "builder_nets":
+        return builder_net_inputs(c["seed"])
     if k == "rays":
         return rays_inputs(c["seed"], R=c.get("R", 48))
     if k in ("render", "render_grad"):

@@ -117,6 +117,8 @@ def run_case(ref, name):
             pass
         elif k == "homo_warp":
             out = run_homo_warp(ref.utils, inp)
+        elif k == "builder_nets":
+            out = run_builder_nets(ref.networks, inp)
         elif k == "rays":
             out = run_rays(ref.utils, c, inp)
         elif k == "render":
@@ -139,6 +141,43 @@ def run_loss_side(ref, inp):
     uv = ref.utils.projection_from_ndc(T(inp["w2c"]), inp["H"], inp["W"], inp["f"], w2, pts)
     (uv * T(inp["gw"])).sum().backward()
     out.update(uv=uv[0].detach().numpy(), uv_dw=w2.grad[0].numpy(), uv_dpts=pts.grad[0].numpy())
+    return out
+
+
+class AbnStandIn(torch.nn.Module):
+    """What is passed to the reference's CostRegNet / FeatureNet as their `norm_act` constructor argument (the classes
+    take the norm as a parameter, networks.py:938-1034; their default, inplace_abn.InPlaceABN, is a CUDA extension that
+    is not installed): batch norm followed by leaky ReLU(0.01), with InPlaceABN's constructor signature and parameter
+    names (inplace_abn 1.1.0: eps 1e-5, momentum 0.1, activation "leaky_relu", activation_param 0.01).  The fixture
+    therefore pins the reference's WIRING of the two stacks - layers, strides, paddings, skip additions, state-dict
+    keys - under this reading of the norm; the norm's own arithmetic stays parity unpinned."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, activation="leaky_relu", activation_param=0.01):
+        super().__init__()
+        self.eps, self.momentum, self.slope = eps, momentum, activation_param
+        self.weight, self.bias = torch.nn.Parameter(torch.ones(num_features)), torch.nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+
+    def forward(self, x):
+        y = torch.nn.functional.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, self.training,
+                                           self.momentum, self.eps)
+        return torch.nn.functional.leaky_relu(y, self.slope)
+
+
+def run_builder_nets(N, inp):
+    """Reference CostRegNet(41) (networks.py:1003-1059) and FeatureNet (networks.py:962-1001), norm_act = AbnStandIn, on
+    the seeded state dicts, in evaluation mode (running estimates) and in training mode (batch statistics)."""
+    out = {}
+    for name, cls, args, x in (("costreg", N.CostRegNet, (41,), T(inp["cost"])), ("feature", N.FeatureNet, (), T(inp["imgs"]))):
+        for mode in ("eval", "train"):
+            net = cls(*args, norm_act=AbnStandIn)
+            missing = net.load_state_dict({k: T(v) for k, v in inp[name + "_state"].items()}, strict=True)
+            assert not missing.missing_keys and not missing.unexpected_keys
+            net.train(mode == "train")
+            y = net(x)
+            y = y[0] if isinstance(y, (tuple, list)) else y
+            out["%s_%s" % (name, mode)] = y.numpy()
     return out
 
 

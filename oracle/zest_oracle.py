@@ -478,6 +478,39 @@ def volume_cost(imgs, feats, proj_mats, depth, pad=0):
     return img_feat, masks
 
 
+def _abn(x, st, prefix, training, eps=1e-5, slope=0.01):
+    """Batch norm (batch statistics in training mode, the running estimates otherwise) + leaky ReLU(0.01): the stated
+    reading of inplace_abn.InPlaceABN (reference networks.py:938-960 passes it as `norm_act`; not installable here)."""
+    y = F.batch_norm(x, None if training else st[prefix + ".running_mean"], None if training else st[prefix + ".running_var"],
+                     st[prefix + ".weight"], st[prefix + ".bias"], True if training else False, 0.0, eps)
+    return F.leaky_relu(y, slope)
+
+
+def cost_reg_net(st, x, training=False):
+    """3-D regularisation net of the volume builder (reference networks.py:1003-1059): x [1,C,D,H,W] -> [1,8,D,H,W].
+    st: state dict with the reference's keys."""
+    def cbr(x, name, stride=1):
+        return _abn(F.conv3d(x, st[name + ".conv.weight"], stride=stride, padding=1), st, name + ".bn", training)
+
+    def up(x, name):
+        return _abn(F.conv_transpose3d(x, st[name + ".0.weight"], stride=2, padding=1, output_padding=1), st, name + ".1", training)
+    c0 = cbr(x, "conv0")
+    c2 = cbr(cbr(c0, "conv1", 2), "conv2")
+    c4 = cbr(cbr(c2, "conv3", 2), "conv4")
+    x = cbr(cbr(c4, "conv5", 2), "conv6")
+    x = c4 + up(x, "conv7")
+    x = c2 + up(x, "conv9")
+    return c0 + up(x, "conv11")
+
+
+def feature_net(st, x, training=False):
+    """2-D feature pyramid of the volume builder (reference networks.py:962-1001): x [N,3,H,W] -> [N,32,H/4,W/4]."""
+    for name, k, stride in (("conv0.0", 3, 1), ("conv0.1", 3, 1), ("conv1.0", 5, 2), ("conv1.1", 3, 1), ("conv1.2", 3, 1),
+                            ("conv2.0", 5, 2), ("conv2.1", 3, 1), ("conv2.2", 3, 1)):
+        x = _abn(F.conv2d(x, st[name + ".conv.weight"], stride=stride, padding=k // 2), st, name + ".bn", training)
+    return F.conv2d(x, st["toplayer.weight"], st["toplayer.bias"])
+
+
 def graf_patch_pixels(H, W, patch_size, step, scale_anneal=-1, min_scale=0.25, max_scale=1.0):
     """Pixel (x, y) indices of GRAF's variable patch.  Restates patch_ray_sampler and the variable_patches branch
     of get_rays_mvs, /root/reference/utils.py:102-131, 157-170: a patch_size^2 lattice over [-1, 1]^2 scaled by

@@ -126,6 +126,11 @@ def run(case, dtype=torch.float32, explicit=True):
             g = zo.plane_grid(T(inp["proj_mats"], dtype)[0, 1], T(inp["depth_values"], dtype)[0], H, W, inp["pad"])
             img_lr = torch.nn.functional.interpolate(imgs, (H, W), mode="bilinear", align_corners=False)
             out = dict(warped=zo.grid_warp(feats[1], g), img_warped=zo.grid_warp(img_lr[1], g))
+        elif k == "builder_nets":
+            for name, fn, x in (("costreg", zo.cost_reg_net, inp["cost"]), ("feature", zo.feature_net, inp["imgs"])):
+                st = {kk: T(v, dtype) for kk, v in inp[name + "_state"].items()}
+                for mode in ("eval", "train"):
+                    out["%s_%s" % (name, mode)] = fn(st, T(x, dtype), training=mode == "train")
         elif k == "rays":
             xs, ys = rays_pixels(c, inp)
             t = lambda a: T(a, dtype)[0]

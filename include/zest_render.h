@@ -173,7 +173,8 @@ int zest_homo_warp_fwd(const float *src, const float *proj, const float *depth, 
  *   taps of the eight output parity classes in the MFMA operand order (zest_networks.CostRegNet packs them);
  *   out [2Di,2Hi,2Wi,cout] raw; stats and passes as above.  Shapes: 64->32, 32->16, 16->8.
  * zest_costreg_bn: pre [2,C] (C <= 64) from the table of batch statistics of `count` voxels (batch_stats != 0; running_mean /
- *   running_var / steps, when given, are updated as nn.BatchNorm does in training mode) or from the running ones.
+ *   running_var / steps, when given, are updated as nn.BatchNorm does in training mode) or from the running ones;
+ *   moments [2,C] or NULL receives mean and 1/sqrt(var + eps) (what a batch-norm backward needs).
  * zest_costreg_out: encoding volume [8,D,H,W] = act(norm(raw_a)) + act(norm(raw_b)) from two [D,H,W,8] tensors.
  * zest_conv2d_fwd: the same kernel on a batch of N images [N,H,W,cin] channels-last - Conv2d(cin -> cout, k, stride,
  *   padding k/2, no bias) on act(norm(in)) (pre NULL: on `in` itself - first layer only), the layers of FeatureNet
@@ -194,7 +195,7 @@ int zest_costreg_deconv_fwd(const float *in0, const float *pre0, const float *in
                             float *out, double *stats, void *stream);
 int zest_costreg_bn(const double *stats, int C, long long count, const float *gamma, const float *beta, float eps,
                     int batch_stats, float *running_mean, float *running_var, float momentum,
-                    long long *steps, float *pre, void *stream);
+                    long long *steps, float *pre, float *moments, void *stream);
 int zest_costreg_out(const float *raw_a, const float *pre_a, const float *raw_b, const float *pre_b, int D,
                      int H, int W, float *volume, void *stream);
 

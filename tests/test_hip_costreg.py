@@ -25,6 +25,7 @@ def _cf(x):            # [D,H,W,C] -> [1,C,D,H,W]
 
 
 def _rel(got, want):
+    got, want = got.detach(), want.detach()
     return float((got - want).abs().max() / want.abs().max().clamp_min(1e-30))
 
 
@@ -238,3 +239,43 @@ def test_builder_takes_the_hip_net_without_a_graph(hip, precision, monkeypatch):
     with amp:
         net(imgs, proj, nf, pad=4)[0].sum().backward()
     assert len(calls) == 1 and net.cost_reg_2.conv0.conv.weight.grad is not None
+
+
+@pytest.mark.parametrize("passes,tol", [(3, 2e-2), (1, 0.35)])
+def test_regularisation_net_trains_through_the_hip_forward(hip, passes, tol):
+    """zest_autograd.CostRegFn: forward on the HIP kernels, backward = the library's backward operators on the kept raw
+    outputs.  Gradients of the input, of every convolution weight and of every norm's weight and bias against plain
+    autograd through the library modules (same weights, training-mode norms).  The two forwards differ by 5e-6 .. 2e-5
+    of a layer's output scale (split-bf16 products; 1e-2 with bf16 operands), so a pre-activation within that distance
+    of zero falls on the other side of the leaky ReLU's kink - 2e-5 of the first layer's 393 k elements here
+    (tools/dbg_costreg_train.py) - and the gradient through it differs by the slope ratio 100: each path is the exact
+    gradient of ITS forward, and the relative L2 difference of two such gradients is sqrt(flipped fraction) ~ 5e-3
+    (layers without a flipped element agree to 1e-5).  Bounds: relative L2 error per gradient tensor 2e-2 with
+    split-bf16 operands, 0.35 with bf16 operands (against the library's bf16 autocast path, itself that far from
+    fp32)."""
+    import zest_autograd
+    import zest_networks as networks
+    torch.manual_seed(21)
+    net, ref = networks.CostRegNet(41).to(DEV).train(), networks.CostRegNet(41).to(DEV).train()
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, networks.ActivatedBatchNorm):
+                m.weight.uniform_(0.5, 1.5), m.bias.normal_(0, 0.2)
+    ref.load_state_dict(net.state_dict())
+    cost = torch.randn(1, 41, 16, 16, 24, device=DEV)
+    g_out = torch.randn(1, 8, 16, 16, 24, device=DEV)
+    ca, cb = cost.clone().requires_grad_(True), cost.clone().requires_grad_(True)
+    amp = torch.autocast("cuda", dtype=torch.bfloat16, enabled=passes == 1)
+    with amp:
+        want = ref(cb)[0].float()
+    want.backward(g_out)
+    got = zest_autograd.costreg_apply(net, ca, passes)
+    got.backward(g_out)
+    assert _rel(got, want) < (1e-3 if passes == 3 else 6e-2)
+    l2 = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
+    assert l2(ca.grad, cb.grad) < tol
+    for (name, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None and l2(p.grad, q.grad) < tol, name
+    for a, b in zip(net.modules(), ref.modules()):                # the running estimates advanced once, as in the library path
+        if isinstance(a, networks.ActivatedBatchNorm):
+            assert int(a.num_batches_tracked) == int(b.num_batches_tracked) == 1

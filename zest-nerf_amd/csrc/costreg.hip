@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_kernel(const DeconvArgs a) 
 // estimates are updated as nn.BatchNorm does: momentum, unbiased variance, the step counter) or from the running ones.
 __global__ __launch_bounds__(1024) void bn_constants_kernel(const double *__restrict__ stats, int C, double count, const float *__restrict__ gamma,
                                     const float *__restrict__ beta, float eps, int batch_stats, float *running_mean,
-                                    float *running_var, float momentum, long long *steps, float *__restrict__ pre) {
+                                    float *running_var, float momentum, long long *steps, float *__restrict__ pre, float *__restrict__ moments) {
     __shared__ double part[1024];
     __shared__ double total[128];
     const int V = 2 * C, G = 1024 / V;           // V values (sum, sum of squares per channel), G row groups (C <= 64)
@@ -467,8 +467,9 @@ __global__ __launch_bounds__(1024) void bn_constants_kernel(const double *__rest
     } else {
         mean = running_mean[c], var = running_var[c];
     }
-    const float scale = (gamma ? gamma[c] : 1.0f) / sqrtf(var + eps);
+    const float invstd = 1.0f / sqrtf(var + eps), scale = (gamma ? gamma[c] : 1.0f) * invstd;
     pre[c] = scale, pre[C + c] = (beta ? beta[c] : 0.0f) - mean * scale;
+    if (moments) moments[c] = mean, moments[C + c] = invstd;         // what a batch-norm backward needs (save_mean, save_invstd)
 }
 
 // encoding volume = act(norm(a)) + act(norm(b)) (the last skip addition), [D,H,W,8] -> the reference's [8,D,H,W]
@@ -612,11 +613,11 @@ extern "C" int zest_costreg_deconv_fwd(const float *in0, const float *pre0, cons
 
 extern "C" int zest_costreg_bn(const double *stats, int C, long long count, const float *gamma, const float *beta, float eps,
                                int batch_stats, float *running_mean, float *running_var, float momentum,
-                               long long *steps, float *pre, void *stream) {
+                               long long *steps, float *pre, float *moments, void *stream) {
     ZEST_CHECK_ARG(pre && C >= 1 && C <= 64 && count >= 1, "zest_costreg_bn: bad argument (at most 64 channels)");
     ZEST_CHECK_ARG(batch_stats ? stats != nullptr : (running_mean && running_var), "zest_costreg_bn: statistics missing");
     hipLaunchKernelGGL(bn_constants_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, stats, C, (double)count, gamma, beta,
-                       eps, batch_stats, running_mean, running_var, momentum, steps, pre);
+                       eps, batch_stats, running_mean, running_var, momentum, steps, pre, moments);
     ZEST_RETURN_LAUNCH("zest_costreg_bn");
 }
 

@@ -345,3 +345,81 @@ class ProjectRaysFn(Function):
         dw, dp = zest_hip.project_rays_bwd(weights, pts, w2c, H, W, focal, g.contiguous(),
                                            ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return dw, dp, None, None, None, None
+
+
+# ------------------------------------------------------------------------------ volume builder: regularisation net
+class CostRegFn(Function):
+    """CostRegNet under autograd with its FORWARD on the HIP kernels (csrc/costreg.hip, 1 ms instead of the library's
+    8-11 ms): the raw output of every layer, its norm constants and batch moments are kept, and the backward pass
+    walks the U-Net in reverse with the library's own backward operators on them (aten.convolution_backward,
+    aten.native_batch_norm_backward; the leaky ReLU and the skip additions are a few elementwise operations).
+    Inputs after `passes`: the ten convolution weights, then (weight, bias) of the ten norms, in layer order."""
+
+    @staticmethod
+    def forward(ctx, cost, net, passes, *params):
+        cl = torch.nn.functional.pad(cost[0].permute(1, 2, 3, 0), (0, zest_hip.COST_CL_CHANNELS - cost.shape[1])).contiguous()
+        vol, raw, pr, mo = net.forward_hip(cl, passes, keep=True)
+        ctx.net, ctx.passes, ctx.n = net, passes, len(raw)
+        ctx.save_for_backward(cost, *raw, *pr, *mo, *params)
+        return vol
+
+    @staticmethod
+    def backward(ctx, g_out):
+        t = ctx.saved_tensors
+        n = ctx.n
+        cost, raw, pr, mo, params = t[0], t[1:1 + n], t[1 + n:1 + 2 * n], t[1 + 2 * n:1 + 3 * n], t[1 + 3 * n:]
+        W, gam = params[:n], params[n::2]
+        net = ctx.net
+        bns = [getattr(net, nm).bn for nm, _ in net._HIP_CONVS] + [getattr(net, nm)[1] for nm in net._HIP_UPS]
+        low = torch.bfloat16 if ctx.passes == 1 else None          # the --precision 16 path: library backward in bf16, as under AMP
+        cf = lambda x: x.permute(3, 0, 1, 2)[None]                  # [D,H,W,C] -> [1,C,D,H,W] (channels-last memory)
+        vec = lambda v: v.view(1, -1, 1, 1, 1)
+
+        def act(i):                                                 # the activation a layer's consumers read
+            return torch.nn.functional.leaky_relu(cf(raw[i]) * vec(pr[i][0]) + vec(pr[i][1]), 0.01)
+
+        def norm_bwd(i, g_a):                                       # through leaky ReLU and the batch norm of layer i
+            r = cf(raw[i])
+            g_y = g_a * torch.where(r * vec(pr[i][0]) + vec(pr[i][1]) > 0, 1.0, 0.01)
+            g_r, g_w, g_b = torch.ops.aten.native_batch_norm_backward(g_y, r, gam[i], None, None, mo[i][0], mo[i][1], True,
+                                                                      float(bns[i].eps), [True, True, True])
+            return g_r, g_w, g_b
+
+        def conv_bwd(g_r, x, w, stride, transposed, want_x=True):
+            if low is not None:
+                g_r, x, w = g_r.to(low), x.to(low), w.to(low)
+            g_x, g_w, _ = torch.ops.aten.convolution_backward(g_r, x, w, None, [stride] * 3, [1] * 3, [1] * 3, transposed,
+                                                              [1 if transposed else 0] * 3, 1, [want_x, True, False])
+            return (g_x.float() if want_x else None), g_w.float()
+        gW, gG, gB = [None] * n, [None] * n, [None] * n
+        g_out = g_out.contiguous()
+        # up path (layers 9, 8, 7 = conv11, conv9, conv7), skip additions on the way
+        g_r, gG[9], gB[9] = norm_bwd(9, g_out)
+        g_x2, gW[9] = conv_bwd(g_r, act(2) + act(8), W[9], 2, True)
+        g_r, gG[8], gB[8] = norm_bwd(8, g_x2)
+        g_x1, gW[8] = conv_bwd(g_r, act(4) + act(7), W[8], 2, True)
+        g_r, gG[7], gB[7] = norm_bwd(7, g_x1)
+        g_a, gW[7] = conv_bwd(g_r, act(6), W[7], 2, True)
+        # down path in reverse (layers 6 .. 0)
+        skip = {4: g_x1, 2: g_x2, 0: g_out}
+        strides = [s for _, s in net._HIP_CONVS]
+        for i in range(6, -1, -1):
+            if i in skip:
+                g_a = g_a + skip[i]
+            g_r, gG[i], gB[i] = norm_bwd(i, g_a)
+            x = act(i - 1) if i > 0 else cost
+            g_a, gW[i] = conv_bwd(g_r, x, W[i], strides[i], False, want_x=(i > 0 or ctx.needs_input_grad[0]))
+        grads = list(gW)
+        for i in range(n):
+            grads += [gG[i], gB[i]]
+        return (g_a, None, None) + tuple(grads)
+
+
+def costreg_apply(net, cost_vol, passes):
+    """CostRegNet(cost_vol [1,41,D,H,W]) -> [1,8,D,H,W] through CostRegFn."""
+    convs = [getattr(net, nm).conv for nm, _ in net._HIP_CONVS] + [getattr(net, nm)[0] for nm in net._HIP_UPS]
+    bns = [getattr(net, nm).bn for nm, _ in net._HIP_CONVS] + [getattr(net, nm)[1] for nm in net._HIP_UPS]
+    params = [c.weight for c in convs]
+    for b in bns:
+        params += [b.weight, b.bias]
+    return CostRegFn.apply(cost_vol.float(), net, passes, *params)

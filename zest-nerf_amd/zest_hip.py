@@ -90,7 +90,7 @@ _SIGS = {
     "zest_costreg_conv_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "zest_costreg_deconv_packed_bytes": (_sz, [_i, _i, _i]),
     "zest_costreg_deconv_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
-    "zest_costreg_bn": (_i, [_vp, _i, C.c_longlong, _vp, _vp, _f, _i, _vp, _vp, _f, _vp, _vp, _vp]),
+    "zest_costreg_bn": (_i, [_vp, _i, C.c_longlong, _vp, _vp, _f, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "zest_costreg_out": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "zest_volume_cost_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "zest_homo_warp_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -432,7 +432,7 @@ def costreg_deconv(x0, pre0, x1, pre1, w_packed, cout, passes, stats):
     return out
 
 
-def costreg_bn(stats, count, bn, batch_stats, pre):
+def costreg_bn(stats, count, bn, batch_stats, pre, moments=None):
     """pre [2,C] <- scale / shift of the batch norm module `bn` (weight, bias, running_*, eps, momentum) from the
     batch statistics `stats` [2,C] of `count` voxels (and the running estimates updated) or from the running ones."""
     Cn = pre.shape[1]
@@ -446,7 +446,7 @@ def costreg_bn(stats, count, bn, batch_stats, pre):
                                  1 if batch_stats else 0, _ptr(bn.running_mean) if track else None,
                                  _ptr(bn.running_var) if track else None, mom,
                                  _ptr(bn.num_batches_tracked) if (track and batch_stats) else None, _ptr(pre),
-                                 _stream(pre)), "zest_costreg_bn")
+                                 _ptr(moments), _stream(pre)), "zest_costreg_bn")
     return pre
 
 

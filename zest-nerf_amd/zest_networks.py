@@ -551,10 +551,12 @@ class CostRegNet(nn.Module):
             return packs
         return _cached_packs(self, passes, ws, build)
 
-    def forward_hip(self, cost_cl, passes=3):
+    def forward_hip(self, cost_cl, passes=3, keep=False):
         """cost_cl [D,H,W,48] channels-last (zest_hip.volume_cost_cl) -> encoding volume [1,8,D,H,W], no graph.
         passes 3: split-bf16 operands (16 significant bits); 1: bf16 operands (the --precision 16 path).  Norms in
-        training mode use (and record) batch statistics, as the library path does."""
+        training mode use (and record) batch statistics, as the library path does.
+        keep: also return what a backward pass needs (zest_autograd.CostRegFn): the raw output of every layer, its norm
+        constants [2,C] and its batch moments [2,C] (mean, 1/std)."""
         D, H, W, _ = cost_cl.shape
         if D % 8 or H % 8 or W % 8:
             raise RuntimeError("CostRegNet.forward_hip: volume %dx%dx%d is not a multiple of 8 per axis" % (D, H, W))
@@ -569,7 +571,9 @@ class CostRegNet(nn.Module):
         pre_all = torch.empty(offs[-1], device=cost_cl.device, dtype=torch.float32)
         st = [stats_all[rows * offs[i]:rows * offs[i + 1]].view(rows, 2, c) for i, c in enumerate(chans)]
         pr = [pre_all[offs[i]:offs[i + 1]].view(2, c) for i, c in enumerate(chans)]
-        norm = lambda i, t: zest_hip.costreg_bn(st[i], t.numel() // chans[i], bns[i], bns[i].training, pr[i])
+        mom_all = torch.empty(offs[-1], device=cost_cl.device, dtype=torch.float32) if keep else None
+        mo = [mom_all[offs[i]:offs[i + 1]].view(2, c) if keep else None for i, c in enumerate(chans)]
+        norm = lambda i, t: zest_hip.costreg_bn(st[i], t.numel() // chans[i], bns[i], bns[i].training, pr[i], mo[i])
         raw, x, pre = [], cost_cl, None
         for i, (name, stride) in enumerate(self._HIP_CONVS):
             x = zest_hip.costreg_conv(x, pre, packs[name], chans[i], stride, passes, st[i])
@@ -577,11 +581,15 @@ class CostRegNet(nn.Module):
             raw.append(x)
         up = zest_hip.costreg_deconv(raw[6], pr[6], None, None, packs["conv7"], chans[7], passes, st[7])
         norm(7, up)
+        raw.append(up)
         up = zest_hip.costreg_deconv(raw[4], pr[4], up, pr[7], packs["conv9"], chans[8], passes, st[8])
         norm(8, up)
+        raw.append(up)
         up = zest_hip.costreg_deconv(raw[2], pr[2], up, pr[8], packs["conv11"], chans[9], passes, st[9])
         norm(9, up)
-        return zest_hip.costreg_out(raw[0], pr[0], up, pr[9])
+        raw.append(up)
+        vol = zest_hip.costreg_out(raw[0], pr[0], up, pr[9])
+        return (vol, raw, pr, mo) if keep else vol
 
     def forward(self, x):
         """-> (encoding volume, the output of every level: three on the way down, the bottom, three on the way up).
@@ -677,9 +685,18 @@ class MVSNet(nn.Module):
                                               proj_mats[0, 1:], depth_values[0], pad, feats_cl=feats_cl)
             return self.cost_reg_2.forward_hip(cost_cl, passes=passes), feats, depth_values
         cost_vol, in_masks = self.build_volume_cost(imgs, feats, proj_mats, depth_values, pad=pad)
+        Dp_ = cost_vol.shape[2]
         if return_color:
             feats = torch.cat((cost_vol[:, :V * 3].view(B, V, 3, *cost_vol.shape[2:]), in_masks.unsqueeze(2)), dim=2)
-        volume_feat, _ = self.cost_reg_2(cost_vol)
+        if (torch.is_grad_enabled() and getattr(self, "zest_hip_costreg_train", False) and cost_vol.is_cuda and B == 1
+                and not (Dp_ % 8 or cost_vol.shape[-2] % 8 or cost_vol.shape[-1] % 8) and self.cost_reg_2.hip_supported()
+                and all(m.training for m in self.cost_reg_2.modules() if isinstance(m, ActivatedBatchNorm))):
+            # opt-in: the regularisation net's FORWARD on the HIP kernels under autograd, its backward from the kept raw
+            # outputs through the library's convolution / batch-norm backward operators (zest_autograd.CostRegFn)
+            import zest_autograd
+            volume_feat = zest_autograd.costreg_apply(self.cost_reg_2, cost_vol, passes)
+        else:
+            volume_feat, _ = self.cost_reg_2(cost_vol)
         volume_feat = volume_feat.reshape(1, -1, *volume_feat.shape[2:])
         return volume_feat, feats, depth_values
 

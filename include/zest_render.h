@@ -196,6 +196,12 @@ int zest_costreg_deconv_fwd(const float *in0, const float *pre0, const float *in
 int zest_costreg_bn(const double *stats, int C, long long count, const float *gamma, const float *beta, float eps,
                     int batch_stats, float *running_mean, float *running_var, float momentum,
                     long long *steps, float *pre, float *moments, void *stream);
+/* Backward of act(norm(raw)) with batch statistics (training; zest_autograd.CostRegFn): raw, g_act, g_raw [M,C]
+ * channels-last (C = 8, 16, 32, 64); pre / moments [2,C] of the forward (zest_costreg_bn); stats: a table as above
+ * (workspace); totals [2,C] receives g_beta = sum g_y and g_gamma = sum g_y xhat. */
+int zest_costreg_bn_bwd(const float *raw, const float *g_act, const float *pre, const float *moments,
+                        const float *gamma, int C, long long M, double *stats, float *totals, float *g_raw,
+                        void *stream);
 int zest_costreg_out(const float *raw_a, const float *pre_a, const float *raw_b, const float *pre_b, int D,
                      int H, int W, float *volume, void *stream);
 

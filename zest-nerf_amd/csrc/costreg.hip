@@ -472,6 +472,94 @@ __global__ __launch_bounds__(1024) void bn_constants_kernel(const double *__rest
     if (moments) moments[c] = mean, moments[C + c] = invstd;         // what a batch-norm backward needs (save_mean, save_invstd)
 }
 
+// ------------------------------------------------------------------------------------- norm backward (training)
+// Backward of act(norm(r)) with batch statistics on the [M, C] view of channels-last tensors (zest_autograd.CostRegFn):
+//   g_y = g_a * (y > 0 ? 1 : 0.01),  xhat = (r - mean) invstd,
+//   g_r = gamma invstd (g_y - sum(g_y) / M - xhat sum(g_y xhat) / M),  g_gamma = sum(g_y xhat),  g_beta = sum(g_y).
+// Pass 1 (reduce): a thread walks float4 quads of its own channel quad (the grid stride is a multiple of C / 4), the
+// lanes of a quad are added by butterflies, the waves in order, one table row per workgroup (kStatRows, as the forward
+// statistics).  Pass 2 (totals): the rows in a fixed order -> [2, C] floats.  Pass 3 (apply): elementwise.
+__device__ __forceinline__ void bn_bwd_terms(const float4 r, const float4 g, const float *sc, const float *sh, const float *mu,
+                                             const float *is, float (&gy)[4], float (&xh)[4]) {
+    const float rv[4] = {r.x, r.y, r.z, r.w}, gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        gy[j] = gv[j] * (fmaf(rv[j], sc[j], sh[j]) > 0.0f ? 1.0f : kSlope);
+        xh[j] = (rv[j] - mu[j]) * is[j];
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float4 *__restrict__ raw, const float4 *__restrict__ g_act,
+                                                            const float *__restrict__ pre, const float *__restrict__ moments,
+                                                            int C, long long n_quads, double *__restrict__ stats) {
+    const int Q = C / 4, q = threadIdx.x % Q;            // Q = 2, 4, 8, 16 divides 256 and the grid stride
+    float sc[4], sh[4], mu[4], is[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        sc[j] = pre[4 * q + j], sh[j] = pre[C + 4 * q + j], mu[j] = moments[4 * q + j], is[j] = moments[C + 4 * q + j];
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_quads; i += (long long)gridDim.x * 256) {
+        float gy[4], xh[4];
+        bn_bwd_terms(raw[i], g_act[i], sc, sh, mu, is, gy, xh);
+#pragma unroll
+        for (int j = 0; j < 4; j++) s1[j] += gy[j], s2[j] = fmaf(gy[j], xh[j], s2[j]);
+    }
+    __shared__ float red[4][2][64];                      // [wave][s1 | s2][channel]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        float a = s1[j], b = s2[j];
+        for (int m = 32; m >= Q; m >>= 1) a += __shfl_xor(a, m, 64), b += __shfl_xor(b, m, 64);
+        if (lane < Q) red[wave][0][4 * lane + j] = a, red[wave][1][4 * lane + j] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * C) {
+        const int which = threadIdx.x / C, c = threadIdx.x % C;
+        stats[((size_t)blockIdx.x * 2 + which) * C + c] =
+            (double)red[0][which][c] + (double)red[1][which][c] + (double)red[2][which][c] + (double)red[3][which][c];
+        if (blockIdx.x == 0 && threadIdx.x == 0) stats[(size_t)kStatRows * 2 * C] = (double)gridDim.x;
+    }
+}
+
+__global__ __launch_bounds__(1024) void bn_bwd_totals_kernel(const double *__restrict__ stats, int C, float *__restrict__ totals) {
+    __shared__ double part[1024];
+    const int V = 2 * C, G = 1024 / V, rows = (int)stats[(size_t)kStatRows * V];
+    const int v = threadIdx.x % V, grp = threadIdx.x / V;
+    double s = 0.0;
+    if (grp < G) {
+#pragma unroll 8
+        for (int r = grp; r < rows; r += G) s += stats[(size_t)r * V + v];
+    }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < V) {
+        double t = 0.0;
+        for (int k = 0; k < G; k++) t += part[k * V + threadIdx.x];
+        totals[threadIdx.x] = (float)t;                  // [0, C): sum g_y = g_beta; [C, 2C): sum g_y xhat = g_gamma
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4 *__restrict__ raw, const float4 *__restrict__ g_act,
+                                                           const float *__restrict__ pre, const float *__restrict__ moments,
+                                                           const float *__restrict__ gamma, const float *__restrict__ totals,
+                                                           int C, long long n_quads, float inv_m, float4 *__restrict__ g_raw) {
+    const int Q = C / 4, q = threadIdx.x % Q;
+    float sc[4], sh[4], mu[4], is[4], k0[4], k1[4], k2[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int c = 4 * q + j;
+        sc[j] = pre[c], sh[j] = pre[C + c], mu[j] = moments[c], is[j] = moments[C + c];
+        k0[j] = (gamma ? gamma[c] : 1.0f) * is[j], k1[j] = totals[c] * inv_m, k2[j] = totals[C + c] * inv_m;
+    }
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_quads; i += (long long)gridDim.x * 256) {
+        float gy[4], xh[4], o[4];
+        bn_bwd_terms(raw[i], g_act[i], sc, sh, mu, is, gy, xh);
+#pragma unroll
+        for (int j = 0; j < 4; j++) o[j] = k0[j] * (gy[j] - k1[j] - xh[j] * k2[j]);
+        g_raw[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // encoding volume = act(norm(a)) + act(norm(b)) (the last skip addition), [D,H,W,8] -> the reference's [8,D,H,W]
 __global__ __launch_bounds__(256) void costreg_out_kernel(const float4 *__restrict__ ra, const float *__restrict__ pa,
                                                           const float4 *__restrict__ rb, const float *__restrict__ pb,
@@ -619,6 +707,22 @@ extern "C" int zest_costreg_bn(const double *stats, int C, long long count, cons
     hipLaunchKernelGGL(bn_constants_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, stats, C, (double)count, gamma, beta,
                        eps, batch_stats, running_mean, running_var, momentum, steps, pre, moments);
     ZEST_RETURN_LAUNCH("zest_costreg_bn");
+}
+
+extern "C" int zest_costreg_bn_bwd(const float *raw, const float *g_act, const float *pre, const float *moments,
+                                   const float *gamma, int C, long long M, double *stats, float *totals, float *g_raw,
+                                   void *stream) {
+    ZEST_CHECK_ARG(raw && g_act && pre && moments && stats && totals && g_raw, "zest_costreg_bn_bwd: null pointer");
+    ZEST_CHECK_ARG((C == 8 || C == 16 || C == 32 || C == 64) && M >= 1, "zest_costreg_bn_bwd: %d channels, %lld voxels", C, M);
+    ZEST_CHECK_ARG(((uintptr_t)raw | (uintptr_t)g_act | (uintptr_t)g_raw) % 16 == 0, "zest_costreg_bn_bwd: pointers must be 16-byte aligned");
+    const long long nq = M * (C / 4);
+    const int grid = nq < 1024ll * 256 ? zest_div_up(nq, 256) : 1024;          // <= kStatRows; 256 % (C / 4) == 0
+    const hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float4 *)raw, (const float4 *)g_act, pre, moments, C, nq, stats);
+    hipLaunchKernelGGL(bn_bwd_totals_kernel, dim3(1), dim3(1024), 0, st, (const double *)stats, C, totals);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, st, (const float4 *)raw, (const float4 *)g_act, pre, moments, gamma,
+                       (const float *)totals, C, nq, 1.0f / (float)M, (float4 *)g_raw);
+    ZEST_RETURN_LAUNCH("zest_costreg_bn_bwd");
 }
 
 extern "C" int zest_costreg_out(const float *raw_a, const float *pre_a, const float *raw_b, const float *pre_b, int D,

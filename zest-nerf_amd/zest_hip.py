@@ -92,6 +92,7 @@ _SIGS = {
     "zest_costreg_deconv_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "zest_costreg_bn": (_i, [_vp, _i, C.c_longlong, _vp, _vp, _f, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "zest_costreg_out": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "zest_costreg_bn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, C.c_longlong, _vp, _vp, _vp, _vp]),
     "zest_volume_cost_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "zest_homo_warp_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "zest_volume_lookup_fwd": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
@@ -448,6 +449,20 @@ def costreg_bn(stats, count, bn, batch_stats, pre, moments=None):
                                  _ptr(bn.num_batches_tracked) if (track and batch_stats) else None, _ptr(pre),
                                  _ptr(moments), _stream(pre)), "zest_costreg_bn")
     return pre
+
+
+def costreg_bn_bwd(raw, g_act, pre, moments, gamma):
+    """Backward of act(norm(raw)) with batch statistics: raw, g_act [..., C] channels-last -> (g_raw like raw,
+    g_gamma [C], g_beta [C])."""
+    raw, g_act = _dev(raw, "raw"), _dev(g_act, "g_act", tuple(raw.shape))
+    Cn = raw.shape[-1]
+    M = raw.numel() // Cn
+    stats = costreg_stats(Cn, raw.device)
+    totals = torch.empty(2, Cn, device=raw.device, dtype=torch.float32)
+    g_raw = torch.empty_like(raw)
+    _check(lib().zest_costreg_bn_bwd(_ptr(raw), _ptr(g_act), _ptr(pre), _ptr(moments), _ptr(gamma), Cn, M, _ptr(stats),
+                                     _ptr(totals), _ptr(g_raw), _stream(raw)), "zest_costreg_bn_bwd")
+    return g_raw, totals[1], totals[0]
 
 
 def costreg_out(raw_a, pre_a, raw_b, pre_b):

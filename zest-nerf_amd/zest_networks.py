@@ -734,6 +734,10 @@ class _Generator(nn.Module):
             if (not train and getattr(self.args, "zest_graph_builders", True) and isinstance(net, MVSNet)
                     and net.feature.hip_supported() and net.hip_path(imgs, self.args.pad)):
                 return self._volume_replayed(net, imgs, proj_mats, near_far)
+            if train and isinstance(net, MVSNet) and not hasattr(net, "zest_hip_costreg_train"):
+                # --precision 16: the regularisation net's forward on the HIP kernels under autograd (CostRegFn; a
+                # whole-generator step 47 -> 31 ms); in fp32 mode the library's fp32 backward dominates either way
+                net.zest_hip_costreg_train = bool(amp and getattr(self.args, "zest_hip_costreg_train", True))
             return net(imgs, proj_mats, near_far, pad=self.args.pad)[0].float()
 
     def _volume_replayed(self, net, imgs, proj_mats, near_far):

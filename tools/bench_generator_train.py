@@ -11,13 +11,14 @@ import test_generators as tg
 ap = argparse.ArgumentParser()
 ap.add_argument("--precision", type=int, default=16)
 ap.add_argument("--steps", type=int, default=5)
-ap.add_argument("--hip-costreg", action="store_true", help="MVSNet.zest_hip_costreg_train: the regularisation nets' forward on the HIP kernels (zest_autograd.CostRegFn)")
+ap.add_argument("--library-costreg", action="store_true", help="MVSNet.zest_hip_costreg_train = False: the regularisation nets through the library under autograd (the product default in --precision 16 is their forward on the HIP kernels, zest_autograd.CostRegFn)")
 a = ap.parse_args()
 torch.backends.cudnn.benchmark = True
 x = tg._batch(7, H=288, W=512)
 args = tg._args(precision=a.precision, N_samples=128, pad=24, batch_size=1024, chunk=1024, num_extra_samples=0, use_motion_mask=False)
 gen = tg._generator(args, train_builders=True).train()
-gen.encoding_net.zest_hip_costreg_train = gen.encoding_net_dy.zest_hip_costreg_train = a.hip_costreg
+if a.library_costreg:
+    gen.encoding_net.zest_hip_costreg_train = gen.encoding_net_dy.zest_hip_costreg_train = False
 
 
 def step():

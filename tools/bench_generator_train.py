@@ -18,7 +18,7 @@ x = tg._batch(7, H=288, W=512)
 args = tg._args(precision=a.precision, N_samples=128, pad=24, batch_size=1024, chunk=1024, num_extra_samples=0, use_motion_mask=False)
 gen = tg._generator(args, train_builders=True).train()
 if a.library_costreg:
-    gen.encoding_net.zest_hip_costreg_train = gen.encoding_net_dy.zest_hip_costreg_train = False
+    args.zest_hip_costreg_train = False
 
 
 def step():

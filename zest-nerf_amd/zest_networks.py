@@ -688,11 +688,15 @@ class MVSNet(nn.Module):
         Dp_ = cost_vol.shape[2]
         if return_color:
             feats = torch.cat((cost_vol[:, :V * 3].view(B, V, 3, *cost_vol.shape[2:]), in_masks.unsqueeze(2)), dim=2)
-        if (torch.is_grad_enabled() and getattr(self, "zest_hip_costreg_train", False) and cost_vol.is_cuda and B == 1
+        # under autograd: the regularisation net's FORWARD on the HIP kernels (zest_autograd.CostRegFn) - by default in
+        # bf16 autocast (--precision 16: a whole-generator step 47 -> 31 ms); in fp32 mode the library's fp32 backward
+        # dominates either way and the library modules are kept unless zest_hip_costreg_train is set
+        hip_train = getattr(self, "zest_hip_costreg_train", None)
+        hip_train = torch.is_autocast_enabled() if hip_train is None else bool(hip_train)
+        if (torch.is_grad_enabled() and hip_train and cost_vol.is_cuda and B == 1
                 and not (Dp_ % 8 or cost_vol.shape[-2] % 8 or cost_vol.shape[-1] % 8) and self.cost_reg_2.hip_supported()
                 and all(m.training for m in self.cost_reg_2.modules() if isinstance(m, ActivatedBatchNorm))):
-            # opt-in: the regularisation net's FORWARD on the HIP kernels under autograd, its backward from the kept raw
-            # outputs through the library's convolution / batch-norm backward operators (zest_autograd.CostRegFn)
+            # backward: HIP norm kernels + the library's convolution backward on the kept raw outputs
             import zest_autograd
             volume_feat = zest_autograd.costreg_apply(self.cost_reg_2, cost_vol, passes)
         else:
@@ -734,10 +738,8 @@ class _Generator(nn.Module):
             if (not train and getattr(self.args, "zest_graph_builders", True) and isinstance(net, MVSNet)
                     and net.feature.hip_supported() and net.hip_path(imgs, self.args.pad)):
                 return self._volume_replayed(net, imgs, proj_mats, near_far)
-            if train and isinstance(net, MVSNet) and not hasattr(net, "zest_hip_costreg_train"):
-                # --precision 16: the regularisation net's forward on the HIP kernels under autograd (CostRegFn; a
-                # whole-generator step 47 -> 31 ms); in fp32 mode the library's fp32 backward dominates either way
-                net.zest_hip_costreg_train = bool(amp and getattr(self.args, "zest_hip_costreg_train", True))
+            if train and isinstance(net, MVSNet) and getattr(self.args, "zest_hip_costreg_train", None) is not None:
+                net.zest_hip_costreg_train = bool(self.args.zest_hip_costreg_train)       # the caller's choice, else MVSNet's default
             return net(imgs, proj_mats, near_far, pad=self.args.pad)[0].float()
 
     def _volume_replayed(self, net, imgs, proj_mats, near_far):

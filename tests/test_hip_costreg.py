@@ -286,3 +286,28 @@ def test_regularisation_net_trains_through_the_hip_forward(hip, passes, tol):
     for a, b in zip(net.modules(), ref.modules()):                # the running estimates advanced once, as in the library path
         if isinstance(a, networks.ActivatedBatchNorm):
             assert int(a.num_batches_tracked) == int(b.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("passes,tol", [(3, 2e-2), (1, 0.35)])
+def test_feature_pyramid_trains_through_the_hip_forward(hip, passes, tol):
+    """zest_autograd.FeatureFn against plain autograd through the library modules; bounds as for the regularisation net."""
+    import zest_autograd
+    import zest_networks as networks
+    torch.manual_seed(23)
+    net, ref = networks.FeatureNet().to(DEV).train(), networks.FeatureNet().to(DEV).train()
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, networks.ActivatedBatchNorm):
+                m.weight.uniform_(0.5, 1.5), m.bias.normal_(0, 0.2)
+    ref.load_state_dict(net.state_dict())
+    imgs = torch.randn(3, 3, 40, 72, device=DEV)
+    g_out = torch.randn(3, 32, 10, 18, device=DEV)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=passes == 1):
+        want = ref(imgs)[0].float()
+    want.backward(g_out)
+    got = zest_autograd.feature_apply(net, imgs, passes)
+    got.backward(g_out)
+    assert tuple(got.shape) == tuple(want.shape) and _rel(got, want) < (1e-3 if passes == 3 else 6e-2)
+    l2 = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
+    for (name, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None and l2(p.grad, q.grad) < tol, name

@@ -424,3 +424,58 @@ def costreg_apply(net, cost_vol, passes):
     for b in bns:
         params += [b.weight, b.bias]
     return CostRegFn.apply(cost_vol.float(), net, passes, *params)
+
+
+class FeatureFn(Function):
+    """FeatureNet under autograd with its forward on the HIP kernels (csrc/costreg.hip, zest_conv2d_fwd), as CostRegFn:
+    norm + activation backward in HIP (zest_costreg_bn_bwd), convolution backward through aten.convolution_backward on
+    the kept raw outputs, the 1x1 top layer as matrix products.  Inputs after `passes`: the eight convolution weights,
+    the top layer's weight and bias, then (weight, bias) of the eight norms."""
+
+    @staticmethod
+    def forward(ctx, imgs, net, passes, *params):
+        feats, raw, pr, mo = net.forward_hip(imgs, passes, keep=True)
+        ctx.net, ctx.passes, ctx.n = net, passes, len(raw)
+        ctx.save_for_backward(imgs, *raw, *pr, *mo, *params)
+        return feats.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g_feats):
+        t = ctx.saved_tensors
+        n = ctx.n
+        imgs, raw, pr, mo, params = t[0], t[1:1 + n], t[1 + n:1 + 2 * n], t[1 + 2 * n:1 + 3 * n], t[1 + 3 * n:]
+        W, top_w, gam = params[:n], params[n], params[n + 2::2]
+        convs = [getattr(ctx.net, s_)[i] for s_, i in ctx.net._HIP_LAYERS]
+        low = torch.bfloat16 if ctx.passes == 1 else None
+        cf = lambda x: x.permute(0, 3, 1, 2)                       # [N,H,W,C] -> [N,C,H,W] (channels-last memory)
+        act = lambda i: torch.nn.functional.leaky_relu(raw[i] * pr[i][0] + pr[i][1], 0.01)
+        g2 = g_feats.permute(0, 2, 3, 1).reshape(-1, 32).float()
+        a7 = act(n - 1).view(-1, 32)
+        g_top_w, g_top_b = (g2.t() @ a7).view_as(top_w), g2.sum(0)
+        g_a = (g2 @ top_w.view(32, 32).float()).view(raw[n - 1].shape)      # channels-last gradient of the last activation
+        gW, gG, gB = [None] * n, [None] * n, [None] * n
+        for i in range(n - 1, -1, -1):
+            g_r, gG[i], gB[i] = zest_hip.costreg_bn_bwd(raw[i], g_a.contiguous(), pr[i], mo[i], gam[i])
+            x = cf(act(i - 1)) if i > 0 else imgs
+            k, s_ = convs[i].conv.kernel_size[0], convs[i].conv.stride[0]
+            go, xi, w = cf(g_r), x, W[i]
+            if low is not None:
+                go, xi, w = go.to(low), xi.to(low), w.to(low)
+            g_x, g_w, _ = torch.ops.aten.convolution_backward(go, xi, w, None, [s_] * 2, [k // 2] * 2, [1, 1], False, [0, 0], 1,
+                                                              [i > 0, True, False])
+            gW[i] = g_w.float()
+            if i > 0:
+                g_a = g_x.float().permute(0, 2, 3, 1)
+        grads = list(gW) + [g_top_w, g_top_b]
+        for i in range(n):
+            grads += [gG[i], gB[i]]
+        return (None, None, None) + tuple(grads)
+
+
+def feature_apply(net, imgs, passes):
+    """FeatureNet(imgs [N,3,H,W]) -> [N,32,H/4,W/4] through FeatureFn."""
+    convs = [getattr(net, s_)[i] for s_, i in net._HIP_LAYERS]
+    params = [m.conv.weight for m in convs] + [net.toplayer.weight, net.toplayer.bias]
+    for m in convs:
+        params += [m.bn.weight, m.bn.bias]
+    return FeatureFn.apply(imgs.float(), net, passes, *params)

@@ -445,8 +445,9 @@ class FeatureNet(nn.Module):
         return (shapes == self._HIP_SHAPES and all(_hip_norm(m.bn) for m in convs) and top.kernel_size == (1, 1)
                 and top.in_channels == top.out_channels == 32)
 
-    def forward_hip(self, imgs, passes=3):
-        """imgs [N,3,H,W] -> top-level features, channels-last [N,H/4,W/4,32] (what the plane sweep reads), no graph."""
+    def forward_hip(self, imgs, passes=3, keep=False):
+        """imgs [N,3,H,W] -> top-level features, channels-last [N,H/4,W/4,32] (what the plane sweep reads), no graph.
+        keep: also the raw output, norm constants and batch moments of every layer (zest_autograd.FeatureFn)."""
         convs = [getattr(self, s)[i] for s, i in self._HIP_LAYERS]
         packs = _cached_packs(self, passes, [m.conv.weight for m in convs],
                               lambda: [pack_conv_weights(m.conv.weight, passes) for m in convs])
@@ -457,16 +458,20 @@ class FeatureNet(nn.Module):
         rows, dev = zest_hip.costreg_stat_rows(), imgs.device
         stats_all = torch.empty(rows * offs[-1], device=dev, dtype=torch.float64)
         pre_all = torch.empty(offs[-1], device=dev, dtype=torch.float32)
+        mom_all = torch.empty(offs[-1], device=dev, dtype=torch.float32) if keep else None
         x = torch.nn.functional.pad(imgs.float().permute(0, 2, 3, 1), (0, 5)).contiguous()        # [N,H,W,8]
-        pre = None
+        pre, raw, pr, mo = None, [], [], []
         for i, m in enumerate(convs):
             st = stats_all[rows * offs[i]:rows * offs[i + 1]].view(rows, 2, chans[i])
             x = zest_hip.conv2d_cl(x, pre, packs[i], chans[i], m.conv.kernel_size[0], m.conv.stride[0], passes, st)
-            pre = zest_hip.costreg_bn(st, x.numel() // chans[i], m.bn, m.bn.training, pre_all[offs[i]:offs[i + 1]].view(2, chans[i]))
+            mom = mom_all[offs[i]:offs[i + 1]].view(2, chans[i]) if keep else None
+            pre = zest_hip.costreg_bn(st, x.numel() // chans[i], m.bn, m.bn.training, pre_all[offs[i]:offs[i + 1]].view(2, chans[i]), mom)
+            raw.append(x), pr.append(pre), mo.append(mom)
         act = torch.nn.functional.leaky_relu(x * pre[0] + pre[1], 0.01)
         top = self.toplayer
         bias = top.bias if top.bias is not None else act.new_zeros(32)
-        return torch.addmm(bias.to(act.dtype), act.view(-1, 32), top.weight.view(32, 32).t().to(act.dtype)).float().view(x.shape)
+        feats = torch.addmm(bias.to(act.dtype), act.view(-1, 32), top.weight.view(32, 32).t().to(act.dtype)).float().view(x.shape)
+        return (feats, raw, pr, mo) if keep else feats
 
     def _upsample_add(self, x, y):
         return torch.nn.functional.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True) + y
@@ -665,9 +670,15 @@ class MVSNet(nn.Module):
         hip = not return_color and self.hip_path(imgs, pad)
         passes = 1 if torch.is_autocast_enabled() else 3
         feats_cl = None
+        hip_train = getattr(self, "zest_hip_costreg_train", None)
+        hip_train = (torch.is_autocast_enabled() if hip_train is None else bool(hip_train)) and torch.is_grad_enabled() and imgs.is_cuda
         if hip and self.feature.hip_supported():
             feats_cl = self.feature.forward_hip(imgs[0], passes)
             feats = feats_cl.permute(0, 3, 1, 2)[None]
+        elif (hip_train and B == 1 and self.feature.hip_supported() and self.feature.toplayer.bias is not None
+              and all(m.training for m in self.feature.modules() if isinstance(m, ActivatedBatchNorm))):
+            import zest_autograd                      # the pyramid's forward on the HIP kernels under autograd (FeatureFn)
+            feats = zest_autograd.feature_apply(self.feature, imgs[0], passes)[None]
         else:
             feats, _ = self.feature(imgs.reshape(B * V, 3, H, W))
             feats = feats.view(B, V, *feats.shape[1:])
@@ -691,9 +702,7 @@ class MVSNet(nn.Module):
         # under autograd: the regularisation net's FORWARD on the HIP kernels (zest_autograd.CostRegFn) - by default in
         # bf16 autocast (--precision 16: a whole-generator step 47 -> 31 ms); in fp32 mode the library's fp32 backward
         # dominates either way and the library modules are kept unless zest_hip_costreg_train is set
-        hip_train = getattr(self, "zest_hip_costreg_train", None)
-        hip_train = torch.is_autocast_enabled() if hip_train is None else bool(hip_train)
-        if (torch.is_grad_enabled() and hip_train and cost_vol.is_cuda and B == 1
+        if (hip_train and B == 1
                 and not (Dp_ % 8 or cost_vol.shape[-2] % 8 or cost_vol.shape[-1] % 8) and self.cost_reg_2.hip_supported()
                 and all(m.training for m in self.cost_reg_2.modules() if isinstance(m, ActivatedBatchNorm))):
             # backward: HIP norm kernels + the library's convolution backward on the kept raw outputs

@@ -762,6 +762,8 @@ class _Generator(nn.Module):
         key = (tuple(imgs.shape), tuple(proj_mats.shape), imgs.dtype, self.args.pad, torch.is_autocast_enabled(), norms,
                str(imgs.device), getattr(net, "zest_hip_costreg", True), tuple(p._version for p in params))
         graphs = self.__dict__.setdefault("_zest_builder_graphs", {})
+        for k in [k for k, e in graphs.items() if e["net"]() is None]:
+            del graphs[k]                                   # a builder that no longer exists: free its graph and buffers
         ent = graphs.get(id(net))
         if (ent is not None and ent["net"]() is net and ent["key"] == key and len(ent["params"]) == len(params)
                 and all(r() is p for r, p in zip(ent["params"], params))):

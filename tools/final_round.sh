@@ -21,3 +21,8 @@ if [ -f zest-nerf_amd/libzest_hip_stamps.so ]; then
   done > $out/${tag}_stamps.txt; cat $out/${tag}_stamps.txt
 fi
 python3 tools/bench_ops.py > $out/${tag}_ops.jsonl 2>/dev/null; cat $out/${tag}_ops.jsonl | cut -c1-160
+# volume builders: the HIP regularisation net / feature pyramid (kernel stats, PMC), and the whole-generator training step
+bash tools/prof_costreg.sh 2>&1 | tail -3
+bash tools/prof_costreg_pmc.sh 1 2>&1 | tail -3
+python3 tools/prof_builder.py --serial > $out/${tag}_builder_hip_costreg_kernels.txt 2>/dev/null; head -3 $out/${tag}_builder_hip_costreg_kernels.txt
+(python3 tools/bench_generator_train.py --precision 16 | head -12; echo "--library-costreg"; python3 tools/bench_generator_train.py --precision 16 --library-costreg | head -8) > $out/${tag}_generator_train_step_hip_costreg.txt 2>/dev/null; head -3 $out/${tag}_generator_train_step_hip_costreg.txt
